@@ -1,0 +1,142 @@
+"""CPU restatement of the reference DeepLabV3/V3+ forward (TEST INFRASTRUCTURE).
+
+Functional style over a flat ``state_dict`` (same 374/629 keys as the reference)
+so that every op on the hot path is visible in one place; backward comes from
+torch autograd over the same stock ATen fp32 ops the reference runs.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from .synth import ArchCfg, synth_state_dict
+
+BN_EPS = 1e-5        # nn.BatchNorm2d default, e.g. network/_deeplab.py:38
+BN_MOMENTUM = 0.1
+
+
+class OracleDeepLab:
+    """Holds the parameters/buffers and evaluates the reference graph.
+
+    forward == _SimpleSegmentationModel.forward (network/utils.py:16-25).
+    """
+
+    def __init__(self, cfg: ArchCfg, state_dict=None, dropout_p=0.1):
+        self.cfg = cfg
+        sd = state_dict if state_dict is not None else synth_state_dict(cfg)
+        self.sd = OrderedDict()
+        for k, v in sd.items():
+            t = v.detach().clone()
+            if t.is_floating_point() and not (k.endswith("running_mean") or k.endswith("running_var")):
+                t.requires_grad_(True)
+            self.sd[k] = t
+        self.training = False
+        self.dropout_p = dropout_p  # nn.Dropout(0.1), network/_deeplab.py:165
+
+    # -- nn.Module-like helpers -------------------------------------------------
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def parameters(self):
+        return [v for v in self.sd.values() if v.requires_grad]
+
+    def named_parameters(self):
+        return [(k, v) for k, v in self.sd.items() if v.requires_grad]
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach()) for k, v in self.sd.items())
+
+    def zero_grad(self):
+        for p in self.parameters():
+            p.grad = None
+
+    # -- building blocks ----------------------------------------------------------
+    def _bn(self, x, prefix):
+        """nn.BatchNorm2d train/eval incl. running-stat update (unbiased var,
+        momentum 0.1) -- e.g. network/backbone/resnet.py:89-93."""
+        sd = self.sd
+        if self.training:
+            sd[prefix + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                            sd[prefix + ".weight"], sd[prefix + ".bias"],
+                            self.training, BN_MOMENTUM, BN_EPS)
+
+    def _conv(self, x, key, stride=1, padding=0, dilation=1, bias=None):
+        return F.conv2d(x, self.sd[key], bias, stride, padding, dilation)
+
+    def _bottleneck(self, x, pre, stride, dilation, down):
+        """Bottleneck.forward, network/backbone/resnet.py:99-120."""
+        out = F.relu(self._bn(self._conv(x, pre + ".conv1.weight"), pre + ".bn1"))
+        out = self._conv(out, pre + ".conv2.weight", stride, dilation, dilation)  # conv3x3 :27-30
+        out = F.relu(self._bn(out, pre + ".bn2"))
+        out = self._bn(self._conv(out, pre + ".conv3.weight"), pre + ".bn3")
+        identity = x
+        if down:
+            identity = self._bn(self._conv(x, pre + ".downsample.0.weight", stride),
+                                pre + ".downsample.1")
+        return F.relu(out + identity)
+
+    def backbone(self, x):
+        """IntermediateLayerGetter.forward over the ResNet children
+        (network/utils.py:78-93, network/backbone/resnet.py:144-155)."""
+        x = self._conv(x, "backbone.conv1.weight", 2, 3)
+        x = F.relu(self._bn(x, "backbone.bn1"))
+        x = F.max_pool2d(x, 3, 2, 1)
+        feats = OrderedDict()
+        for li, L in enumerate(self.cfg.layers()):
+            for bi, d in enumerate(L["dils"]):
+                pre = "backbone.layer%d.%d" % (li + 1, bi)
+                x = self._bottleneck(x, pre, L["stride"] if bi == 0 else 1, d,
+                                     L["down"] and bi == 0)
+            if li == 0:
+                feats["low_level"] = x
+        feats["out"] = x
+        return feats
+
+    def aspp(self, x, ap):
+        """ASPP.forward, network/_deeplab.py:143-172 (ASPPConv :121-128,
+        ASPPPooling :130-141)."""
+        res = [F.relu(self._bn(self._conv(x, ap + ".convs.0.0.weight"), ap + ".convs.0.1"))]
+        for i, r in zip((1, 2, 3), self.cfg.aspp_dilate):
+            y = self._conv(x, ap + ".convs.%d.0.weight" % i, 1, r, r)
+            res.append(F.relu(self._bn(y, ap + ".convs.%d.1" % i)))
+        size = x.shape[-2:]
+        p = F.adaptive_avg_pool2d(x, 1)
+        p = F.relu(self._bn(self._conv(p, ap + ".convs.4.1.weight"), ap + ".convs.4.2"))
+        res.append(F.interpolate(p, size=size, mode="bilinear", align_corners=False))
+        y = torch.cat(res, dim=1)
+        y = F.relu(self._bn(self._conv(y, ap + ".project.0.weight"), ap + ".project.1"))
+        return F.dropout(y, self.dropout_p, self.training)
+
+    def head(self, feats):
+        c = "classifier"
+        if self.cfg.name == "deeplabv3plus":
+            # DeepLabHeadV3Plus.forward, network/_deeplab.py:55-61
+            low = F.relu(self._bn(self._conv(feats["low_level"], c + ".project.0.weight"),
+                                  c + ".project.1"))
+            y = self.aspp(feats["out"], c + ".aspp")
+            y = F.interpolate(y, size=low.shape[2:], mode="bilinear", align_corners=False)
+            y = torch.cat([low, y], dim=1)
+            y = F.relu(self._bn(self._conv(y, c + ".classifier.0.weight", 1, 1), c + ".classifier.1"))
+            y = F.relu(self._bn(self._conv(y, c + ".classifier.3.weight", 1, 1), c + ".classifier.4"))
+            return self._conv(y, c + ".classifier.6.weight", bias=self.sd[c + ".classifier.6.bias"])
+        # DeepLabHead.forward, network/_deeplab.py:71-93
+        y = self.aspp(feats["out"], c + ".classifier.0")
+        y = F.relu(self._bn(self._conv(y, c + ".classifier.1.weight", 1, 1), c + ".classifier.2"))
+        return self._conv(y, c + ".classifier.4.weight", bias=self.sd[c + ".classifier.4.bias"])
+
+    def forward(self, x):
+        input_shape = x.shape[-2:]
+        y = self.head(self.backbone(x))
+        return F.interpolate(y, size=input_shape, mode="bilinear", align_corners=False)
+
+    __call__ = forward
+
+
+def argmax_mask(logits):
+    """``logits.max(1)[1]`` -- train.py:644,659; ties resolve to the lowest index."""
+    return logits.max(1)[1]

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle (oracle/) against vectors produced by the reference's own
+code (oracle/make_golden.py -> tests/golden/).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import loss as oloss
+from oracle import optim as ooptim
+from oracle.deeplab import OracleDeepLab, argmax_mask
+from oracle.make_golden import (BILINEAR_CASES, BOTTLENECK_CASES, FOCAL_CASES, LOSS_CASES, MODEL_CASES,
+                                WATCH, upstream)
+from oracle.synth import (ArchCfg, aspp_shapes, bottleneck_shapes, head_v3plus_shapes, synth_from_shapes,
+                          synth_images, synth_labels, synth_state_dict, synth_tensor)
+from tests.util import check, check_grad, load, rel_err
+
+TOL = 2e-5   # oracle and reference run the same ATen CPU ops; only op order differs
+
+
+def _oracle(sd, rates=(6, 12, 18)):
+    cfg = ArchCfg(output_stride=16 if tuple(rates) == (6, 12, 18) else 8)
+    return OracleDeepLab(cfg, sd, dropout_p=0.0)
+
+
+@pytest.mark.parametrize("tag,rates,hw", [("os16_17", (6, 12, 18), 17), ("os16_25", (6, 12, 18), 25),
+                                          ("os8_41", (12, 24, 36), 41)])
+def test_aspp(tag, rates, hw):
+    fx = load("aspp_%s.npz" % tag)
+    o = _oracle(synth_from_shapes(aspp_shapes("aspp", 64)), rates)
+    x = synth_images(2, hw, hw, seed=11, c=64)
+    check(o.eval().aspp(x, "aspp"), fx, "eval_out", TOL)
+    o.train()
+    xg = x.clone().requires_grad_(True)
+    y = o.aspp(xg, "aspp")
+    check(y, fx, "train_out", TOL)
+    (y * upstream(y.shape, 5)).sum().backward()
+    check(xg.grad, fx, "grad_x", TOL)
+    for k, p in o.named_parameters():
+        check_grad(p.grad, fx, "grad." + k[len("aspp."):], 1e-4)
+    for k in fx.files:
+        if k.startswith("buf."):
+            assert rel_err(o.sd["aspp." + k[4:]], fx[k]) <= TOL, k
+
+
+def test_head_v3plus():
+    fx = load("head_v3plus.npz")
+    sd = synth_from_shapes(head_v3plus_shapes("classifier", 64, 16, 2))
+    o = _oracle(sd)
+    low = synth_images(2, 65, 65, seed=21, c=16)
+    hi = synth_images(2, 17, 17, seed=22, c=64)
+    check(o.eval().head({"low_level": low, "out": hi}), fx, "eval_out", TOL)
+    o.train()
+    lg, hg = low.clone().requires_grad_(True), hi.clone().requires_grad_(True)
+    y = o.head({"low_level": lg, "out": hg})
+    check(y, fx, "train_out", TOL)
+    (y * upstream(y.shape, 6)).sum().backward()
+    check(lg.grad, fx, "grad_low", 1e-4)
+    check(hg.grad, fx, "grad_out", 1e-4)
+    for k, p in o.named_parameters():
+        check_grad(p.grad, fx, "grad." + k[len("classifier."):], 1e-4)
+
+
+@pytest.mark.parametrize("tag", list(BOTTLENECK_CASES))
+def test_bottleneck(tag):
+    fx = load("bottleneck.npz")
+    inpl, pl, s, d, down, hw = BOTTLENECK_CASES[tag]
+    o = _oracle(synth_from_shapes(bottleneck_shapes("block", inpl, pl, down)))
+    x = synth_images(2, hw, hw, seed=31, c=inpl)
+    check(o.eval()._bottleneck(x, "block", s, d, down), fx, tag + ".eval_out", TOL)
+    o.train()
+    xg = x.clone().requires_grad_(True)
+    y = o._bottleneck(xg, "block", s, d, down)
+    check(y, fx, tag + ".train_out", TOL)
+    (y * upstream(y.shape, 7)).sum().backward()
+    check(xg.grad, fx, tag + ".grad_x", 1e-4)
+    for k, p in o.named_parameters():
+        check_grad(p.grad, fx, tag + ".grad." + k[len("block."):], 1e-4)
+    for k in fx.files:
+        if k.startswith(tag + ".buf."):
+            assert rel_err(o.sd["block." + k[len(tag) + 5:]], fx[k]) <= TOL, k
+
+
+def test_stem():
+    fx = load("stem.npz")
+    sd = {k: synth_tensor(k, s) for k, s in [("backbone.conv1.weight", (64, 3, 7, 7)),
+                                              ("backbone.bn1.weight", (64,)), ("backbone.bn1.bias", (64,)),
+                                              ("backbone.bn1.running_mean", (64,)),
+                                              ("backbone.bn1.running_var", (64,)),
+                                              ("backbone.bn1.num_batches_tracked", ())]}
+    o = _oracle(sd).train()
+    x = synth_images(2, 65, 65, seed=41).requires_grad_(True)
+    y = F.max_pool2d(F.relu(o._bn(o._conv(x, "backbone.conv1.weight", 2, 3), "backbone.bn1")), 3, 2, 1)
+    check(y, fx, "train_out", TOL)
+    (y * upstream(y.shape, 8)).sum().backward()
+    check(x.grad, fx, "grad_x", 1e-4)
+    check_grad(o.sd["backbone.conv1.weight"].grad, fx, "grad.conv1.weight", 1e-4)
+    check_grad(o.sd["backbone.bn1.weight"].grad, fx, "grad.bn1.weight", 1e-4)
+
+
+@pytest.mark.parametrize("c", [2, 5])
+def test_losses(c):
+    fx = load("loss.npz")
+    logits0 = synth_images(2, 65, 65, seed=61, c=c) * 2.0
+    labels = torch.from_numpy(fx["c%d.labels" % c].astype(np.int64))
+    for tag, w in LOSS_CASES:
+        wt = None if w is None else torch.tensor((w * 3)[:c], dtype=torch.float32)
+        lg = logits0.clone().requires_grad_(True)
+        val = oloss.weighted_ce(lg, labels, wt, 255)
+        val.backward()
+        assert rel_err(val, fx["c%d.%s.value" % (c, tag)]) <= TOL
+        assert rel_err(lg.grad, fx["c%d.%s.grad" % (c, tag)]) <= TOL
+        for alpha, gamma, avg in FOCAL_CASES:
+            lg = logits0.clone().requires_grad_(True)
+            val = oloss.focal_loss(lg, labels, alpha, gamma, avg, 255, wt)
+            val.backward()
+            key = "c%d.focal_a%g_g%g_%s_%s" % (c, alpha, gamma, "mean" if avg else "sum", tag)
+            assert rel_err(val, fx[key + ".value"]) <= TOL, key
+            assert rel_err(lg.grad, fx[key + ".grad"]) <= 1e-4, key
+
+
+def test_class_weights():
+    """train.py:388-410 cannot be imported (mlflow etc. absent); formula restated and
+    checked on the bench's 10 % foreground case: sqrt(0.9/0.1) = 3."""
+    lab = torch.zeros(10, 10, dtype=torch.int64)
+    lab[0] = 1
+    w = oloss.class_weights(lab)
+    assert w.dtype == torch.float32 and w[0] == 1.0 and abs(float(w[1]) - 3.0) < 1e-6
+
+
+@pytest.mark.parametrize("tag,backbone,os_", MODEL_CASES)
+def test_whole_model(tag, backbone, os_):
+    fx = load("model_%s.npz" % tag)
+    cfg = ArchCfg("deeplabv3plus", backbone, 2, os_)
+    o = OracleDeepLab(cfg, synth_state_dict(cfg), dropout_p=0.0)
+    x = synth_images(2, 65, 65, seed=71)
+    labels = torch.from_numpy(fx["labels"].astype(np.int64))
+    with torch.no_grad():
+        lg = o.eval()(x)
+    assert rel_err(lg, fx["eval_logits"]) <= 1e-4
+    mask = argmax_mask(lg).numpy()
+    margin = np.abs(fx["eval_logits"][:, 1] - fx["eval_logits"][:, 0])
+    sure = margin > 1e-4 * np.abs(fx["eval_logits"]).max()
+    assert (mask[sure] == fx["eval_mask"][sure]).all()
+    o.train()
+    lg = o(x)
+    assert rel_err(lg, fx["train_logits"]) <= 1e-4
+    loss = oloss.weighted_ce(lg, labels, torch.tensor([1.0, 3.0]), 255)
+    assert rel_err(loss, fx["loss"]) <= 1e-5
+    loss.backward()
+    for k in WATCH:
+        check_grad(o.sd[k].grad, fx, "grad." + k, 1e-3)
+    for k in fx.files:
+        if k.startswith("buf."):
+            assert rel_err(o.sd[k[4:]], fx[k]) <= 1e-4, k
+
+
+@pytest.mark.parametrize("oname", ["sgd", "adam", "adamw"])
+def test_optimizers(oname):
+    """setup_optimizer + setup_scheduler arithmetic, train.py:421-452."""
+    from oracle.make_golden import OPTIM_STEPS, optim_inputs
+    fx = load("optim.npz")
+    params, grads = optim_inputs()
+    ps = [v.clone().requires_grad_(True) for v in params.values()]
+    opt = {"sgd": lambda: ooptim.OracleSGD(ps), "adam": lambda: ooptim.OracleAdam(ps, decoupled=False),
+           "adamw": lambda: ooptim.OracleAdam(ps, decoupled=True)}[oname]()
+    for t in range(OPTIM_STEPS):
+        for p, g in zip(ps, grads[t].values()):
+            p.grad = g.clone()
+        opt.step()
+        opt.lr = ooptim.cosine_lr(1e-3, t + 1, 10, 1e-4)
+    for k, p in zip(params, ps):
+        assert rel_err(p, fx["%s.%s" % (oname, k)]) <= 2e-6, k
+    assert math.isclose(opt.lr, float(fx["%s.lr" % oname]), rel_tol=1e-6)
+
+
+def test_cosine_lr_matches_torch():
+    """CosineAnnealingLR(T_max, eta_min=lr*0.01), train.py:446-452."""
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], momentum=0.9)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50, eta_min=0.01 * 0.01)
+    for t in range(1, 40):
+        opt.step()
+        sch.step()
+        assert math.isclose(opt.param_groups[0]["lr"], ooptim.cosine_lr(1e-3, t, 50, 1e-4), rel_tol=1e-6)
