@@ -1,0 +1,184 @@
+/*
+ * iswm_hip.h -- C ABI of libiswm_hip.so, the MI355X (gfx950) kernels behind the
+ * DeepLabV3+ training hot path of Alanlee0323/ISWM.
+ *
+ * The reference has no FFI layer of its own: its hot path is a chain of stock
+ * torch.nn modules.  Each entry point below replaces the ATen op
+ * that one reference call site runs; the call site is cited next to it (paths
+ * relative to the reference checkout).  The host side (iswm_amd/, Python) binds
+ * these with ctypes -- plain pointers and sizes, no torch types.
+ *
+ * Conventions
+ *   - all tensors are device pointers to fp32 unless stated otherwise;
+ *   - activations are NHWC ("channels last"): element (n,h,w,c) of a tensor with
+ *     pixel pitch ld lives at ((n*H+h)*W+w)*ld + c.  ld >= C lets an op read or
+ *     write a channel slice of a wider buffer;
+ *   - conv weights are OHWI: [Cout][KH][KW][Cin] (a torch [Cout,Cin,KH,KW]
+ *     parameter in channels_last memory format has exactly this layout);
+ *   - every function enqueues on `stream` and returns immediately; it never
+ *     synchronises, allocates or frees (safe under hipGraph capture);
+ *   - return 0 on success, non-zero on a rejected argument or a launch error;
+ *     iswm_last_error() then holds a thread-local message.
+ */
+#ifndef ISWM_HIP_H
+#define ISWM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* iswm_stream_t; /* hipStream_t */
+
+const char* iswm_last_error(void);
+int iswm_version(void);
+
+/* ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) ------------------
+ * nn.Conv2d call sites: network/backbone/resnet.py:27-35,144,184-187;
+ * network/_deeplab.py:37,44-51,124,134,149,162.  groups == 1, square dilation.
+ * Requirements: Cin % 4 == 0, Cout % 4 == 0, ldx % 4 == 0, ldy % 4 == 0,
+ * 16-byte aligned pointers (the host pads the 3-channel stem input to 4 and the
+ * num_classes-wide classifier to a multiple of 4). */
+typedef struct {
+    int N, H, W, Cin;   /* input  [N,H,W,Cin]  */
+    int Ho, Wo, Cout;   /* output [N,Ho,Wo,Cout] */
+    int KH, KW, stride, pad, dil;
+    int ldx;            /* pixel pitch of x  (floats) */
+    int ldy;            /* pixel pitch of y  (floats) */
+} iswm_conv_desc;
+
+/* number of 128-row M tiles of the forward kernel == rows of the BN partials */
+int iswm_conv2d_stat_tiles(const iswm_conv_desc* d);
+/* y = conv(x, w) (+ bias).  If stat_partials != NULL it receives per-M-tile
+ * per-channel sums: [2][tiles][Cout] = {sum y, sum y*y} for the training-mode
+ * BatchNorm that follows every conv (network/backbone/resnet.py:89-93). */
+int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const float* w, const float* bias,
+                    float* y, float* stat_partials, iswm_stream_t stream);
+/* dx (=|+=) conv_transpose(dy, w): autograd backward of the conv wrt its input;
+ * accumulate != 0 adds into dx (branches that share an input, residual joins) */
+int iswm_conv2d_dgrad(const iswm_conv_desc* d, const float* dy, const float* w, float* dx,
+                      int accumulate, iswm_stream_t stream);
+/* dw[Cout][KH][KW][Cin] = sum over pixels.  workspace holds split-K slabs. */
+size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d);
+int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const float* dy, float* dw,
+                      float* workspace, size_t workspace_bytes, iswm_stream_t stream);
+
+/* ---- BatchNorm2d (training and eval), ReLU, residual add ---------------------
+ * nn.BatchNorm2d eps 1e-5 momentum 0.1 + nn.ReLU + FloatFunctional.add:
+ * network/backbone/resnet.py:99-120, network/_deeplab.py:38-39,125-126,135-136. */
+/* per-channel partial sums of a [M, C] (pitch ld) tensor: out[2][tiles][C]; returns
+ * tiles through iswm_colstat_tiles(M). */
+int iswm_colstat_tiles(int64_t M);
+int iswm_colstat(const float* x, int64_t M, int C, int ld, float* partials, iswm_stream_t stream);
+/* reduce partials -> batch mean / biased var, update running stats (unbiased var,
+ * momentum), emit scale = gamma*invstd, shift = beta - mean*scale, and save
+ * mean / invstd for backward. */
+int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                     iswm_stream_t stream);
+/* eval mode: scale/shift from the running statistics */
+int iswm_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift,
+                        float* save_mean, float* save_invstd, iswm_stream_t stream);
+/* out = act(y*scale[c] + shift[c] (+ residual)); act = relu if relu != 0 */
+int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift,
+                  const float* residual, int ldr, int relu, float* out, int ldo,
+                  iswm_stream_t stream);
+/* backward, stage 1: dz = dout * (out > 0 if relu); partial sums of dz and dz*xhat:
+ * partials[2][tiles][C] with tiles = iswm_colstat_tiles(M) */
+int iswm_bn_bwd_reduce(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
+                       int64_t M, int C, const float* mean, const float* invstd, int relu,
+                       float* partials, iswm_stream_t stream);
+/* stage 2: finalize dgamma/dbeta from the partials, then
+ * dy = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzxhat/M) (training) or gamma*invstd*dz (eval);
+ * dres (optional) = dz for the identity branch. */
+int iswm_bn_bwd_finalize(const float* partials, int tiles, int C, float* dgamma, float* dbeta,
+                         iswm_stream_t stream);
+int iswm_bn_bwd_apply(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
+                      int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                      const float* dgamma, const float* dbeta, int relu, int training, float* dy,
+                      int lddy, float* dres, int lddres, iswm_stream_t stream);
+
+/* ---- pooling ------------------------------------------------------------------ */
+/* nn.MaxPool2d(3, 2, 1), network/backbone/resnet.py:148.  idx[n,ho,wo,c] = winning
+ * tap 0..8 (first max in scan order, as ATen). */
+int iswm_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, uint8_t* idx, int Ho,
+                          int Wo, iswm_stream_t stream);
+int iswm_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, int N, int H, int W, int C, int Ho,
+                          int Wo, float* dx, iswm_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1), network/_deeplab.py:133: y[n,c] = mean over HW */
+int iswm_gap_fwd(const float* x, int N, int HW, int C, int ldx, float* y, iswm_stream_t stream);
+/* dx[n,p,c] (+)= dy[n,c]/HW  (accumulate != 0 adds into dx) */
+int iswm_gap_bwd(const float* dy, int N, int HW, int C, float* dx, int lddx, int accumulate,
+                 iswm_stream_t stream);
+/* broadcast a [N,C] vector over HW pixels (bilinear upsample of a 1x1 map,
+ * network/_deeplab.py:141) into a channel slice, and its backward (sum over HW) */
+int iswm_bcast_fwd(const float* v, int N, int HW, int C, float* y, int ldy, iswm_stream_t stream);
+int iswm_bcast_bwd(const float* dy, int lddy, int N, int HW, int C, float* dv, iswm_stream_t stream);
+
+/* ---- bilinear resize, align_corners=False ------------------------------------
+ * F.interpolate call sites: network/_deeplab.py:58, network/utils.py:22. */
+int iswm_bilinear_fwd(const float* x, int N, int Hi, int Wi, int C, int ldx, float* y, int Ho, int Wo,
+                      int ldy, iswm_stream_t stream);
+int iswm_bilinear_bwd(const float* dy, int N, int Hi, int Wi, int C, int lddy, int Ho, int Wo, float* dx,
+                      int lddx, iswm_stream_t stream);
+/* final upsample fused with the NHWC -> NCHW layout change of the logits
+ * (network/utils.py:22-24): x NHWC [N,Hi,Wi,ldx] (first C channels) -> y NCHW */
+int iswm_bilinear_nhwc_to_nchw_fwd(const float* x, int N, int Hi, int Wi, int C, int ldx, float* y,
+                                   int Ho, int Wo, iswm_stream_t stream);
+int iswm_bilinear_nhwc_to_nchw_bwd(const float* dy, int N, int Hi, int Wi, int C, int lddx, int Ho,
+                                   int Wo, float* dx, iswm_stream_t stream);
+
+/* ---- layout / elementwise helpers ---------------------------------------------- */
+/* NCHW [N,C,H,W] -> NHWC with Cp >= C channels (extra channels zero) */
+int iswm_nchw_to_nhwc(const float* x, int N, int C, int HW, float* y, int Cp, iswm_stream_t stream);
+int iswm_nhwc_to_nchw(const float* x, int N, int C, int HW, int ldx, float* y, iswm_stream_t stream);
+/* copy C channels between pitched [M, *] buffers (torch.cat / its backward,
+ * network/_deeplab.py:59,171) */
+int iswm_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t M, int C,
+                       iswm_stream_t stream);
+int iswm_add_inplace(float* dst, const float* src, int64_t n, iswm_stream_t stream);
+int iswm_scale_inplace(float* x, int64_t n, const float* scalar_dev, float host_mul, iswm_stream_t stream);
+/* nn.Dropout(p), network/_deeplab.py:165: counter-based Philox mask */
+int iswm_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                     uint64_t offset, iswm_stream_t stream);
+int iswm_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p,
+                     iswm_stream_t stream);
+
+/* ---- fused weighted cross-entropy / focal loss ---------------------------------
+ * nn.CrossEntropyLoss(weight, ignore_index=255), train.py:454-459 and
+ * FocalLoss.forward, utils/loss.py:23-35.  logits NCHW [B,C,H,W]; labels uint8 or
+ * int64 [B,H,W].  mode 0: weighted mean (CE); 1: focal mean over all pixels;
+ * 2: focal sum.  One pass writes the UNNORMALISED gradient and per-block partial
+ * sums {sum w*nll or sum focal, sum w}; iswm_loss_finalize reduces them into
+ * sums[2] and loss[1] (deterministic two-stage reduction). */
+int iswm_loss_blocks(int64_t npix);
+int iswm_loss_fwd(const float* logits, const void* labels, int label_bytes, int B, int C, int64_t HW,
+                  const float* class_weight, int ignore_index, float alpha, float gamma, int mode,
+                  float* grad_unnorm, float* partials, iswm_stream_t stream);
+int iswm_loss_finalize(const float* partials, int blocks, int mode, int64_t npix, float* sums,
+                       float* loss, iswm_stream_t stream);
+/* grad *= upstream * (mode 0: 1/sums[1]; mode 1: 1/npix; mode 2: 1) */
+int iswm_loss_bwd_scale(float* grad, int64_t n, const float* sums, const float* upstream, int mode,
+                        int64_t npix, iswm_stream_t stream);
+/* logits.max(1)[1], train.py:644,659 -- ties resolve to the lowest class index */
+int iswm_argmax_nchw(const float* logits, int B, int C, int64_t HW, int64_t* out, iswm_stream_t stream);
+
+/* ---- optimizers over a flat fp32 arena ------------------------------------------
+ * torch.optim.SGD(momentum=0.9, nesterov=True, weight_decay) / Adam / AdamW as built
+ * by setup_optimizer, train.py:421-444.  lr is read from device memory so that a
+ * captured graph can be replayed with a new learning rate. */
+int iswm_sgd_step(float* p, const float* g, float* buf, int64_t n, const float* lr_dev, float momentum,
+                  float weight_decay, int nesterov, iswm_stream_t stream);
+/* hyper_dev[4] = {lr, bias_correction1, bias_correction2, unused} */
+int iswm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev,
+                   float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                   iswm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISWM_HIP_H */

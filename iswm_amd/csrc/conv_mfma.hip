@@ -1,0 +1,656 @@
+// Implicit-GEMM 2-D convolution for gfx950 on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32: forward, data gradient and weight gradient.
+//
+// Replaces the nn.Conv2d calls of the reference hot path (network/backbone/resnet.py:27-35,
+// 144,184-187; network/_deeplab.py:37,44-51,124,134,149,162) and their autograd backward.
+//
+// Design:
+//   * activations NHWC, weights OHWI: the GEMM K axis (tap, channel) is contiguous in
+//     memory for both operands of the forward pass, so tiles are staged with 16-byte
+//     loads and no im2col buffer ever exists;
+//   * one workgroup = 4 waves (2x2), block tile 128 x {128,64} x 32, each wave owns a
+//     64 x {64,32} sub-tile as 32x32 MFMA accumulators; two workgroups per CU;
+//   * global -> register -> LDS staging, double-buffered in LDS, one barrier per K chunk:
+//     the loads of chunk k+1 are issued before the MFMAs of chunk k and written to the
+//     other LDS buffer after them;
+//   * an operand whose K axis is contiguous in memory ("KC": activations / OHWI weights
+//     in fwd, dy in dgrad) is kept [row][k] in LDS with a 36-float row pitch and read as
+//     ds_read_b128 (conflict-free: 16 rows x 144 B hit 16 distinct 16-byte slots); one
+//     b128 read feeds 4 MFMAs (lane half h supplies k = 4h+j for MFMA j);
+//   * an operand whose ROW axis is contiguous ("RC": weights in dgrad, dy and x in
+//     wgrad) is kept [k][row] and read with ds_read_b32 (32 consecutive floats per half);
+//   * padding taps are zero-filled at load time; dilation is just a tap offset;
+//   * the forward epilogue optionally emits per-tile per-channel sum / sum-of-squares for
+//     the training-mode BatchNorm that follows every conv (deterministic two-stage stats);
+//   * wgrad flattens (tap, cin) into the GEMM N axis and splits the pixel (K) axis across
+//     workgroups into slabs that a second kernel sums in a fixed order (bit-reproducible).
+#include "common.h"
+
+namespace iswm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    float* stats;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, ldx, ldy;
+    int M;       // GEMM rows
+    int Ktot;    // GEMM K (fwd/dgrad) or flattened N (wgrad)
+    int MT, NT;  // tile counts
+    int nsplit;  // wgrad: K splits
+    int psplit;  // wgrad: pixels per split (multiple of 32)
+    int accumulate;  // dgrad: dx += result instead of dx = result
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+constexpr int KC_PITCH = 36;  // floats per LDS row of a K-contiguous operand tile (32 + 4 pad)
+
+// ------------------------------------------------------------------------------------------
+// forward:  y[m, co] = sum_k A[m, k] * W[co, k],  m = (n, oh, ow),  k = (kh, kw, ci)
+// ------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv_fwd(const ConvArgs a) {
+    constexpr int BM = 128;
+    constexpr int NB = BN / 64;    // 32-wide MFMA column tiles per wave
+    constexpr int BROWS = BN / 32; // weight rows staged per thread
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * KC_PITCH];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * KC_PITCH;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L / a.NT, nt = L - mt * a.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int q = t & 7, r0 = t >> 3;
+
+    const int HoWo = a.Ho * a.Wo;
+    int ihb[4], iwb[4], pb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int m = m0 + r0 + 32 * j;
+        if (m < a.M) {
+            int n = m / HoWo, rem = m - n * HoWo;
+            int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            ihb[j] = oh * a.stride - a.pad;
+            iwb[j] = ow * a.stride - a.pad;
+            pb[j] = n * a.H * a.W;
+        } else {
+            ihb[j] = -(1 << 28);
+            iwb[j] = 0;
+            pb[j] = 0;
+        }
+    }
+    const int Cin4 = a.Cin >> 2, K4 = a.Ktot >> 2;
+    const float* wrow[BROWS];
+    bool wok[BROWS];
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+        int n = n0 + r0 + 32 * j;
+        wok[j] = n < a.Cout;
+        wrow[j] = a.w + (size_t)(wok[j] ? n : 0) * a.Ktot;
+    }
+
+    float4 ra[4], rb[BROWS];
+    auto gload = [&](int kc) {
+        const int k4 = kc * 8 + q;
+        const bool kv = k4 < K4;
+        const int tap = k4 / Cin4, c4 = k4 - tap * Cin4;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int dh = kh * a.dil, dw = kw * a.dil;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ih = ihb[j] + dh, iw = iwb[j] + dw;
+            bool ok = kv && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            ra[j] = ok ? ldg4(a.x + (size_t)(pb[j] + ih * a.W + iw) * a.ldx + c4 * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+            rb[j] = (kv && wok[j]) ? ldg4(wrow[j] + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(&As[(buf * BM + r0 + 32 * j) * KC_PITCH + q * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+            *reinterpret_cast<float4*>(&Bs[(buf * BN + r0 + 32 * j) * KC_PITCH + q * 4]) = rb[j];
+    };
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nK = (a.Ktot + 31) >> 5;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nK; ++kc) {
+        const int cur = kc & 1;
+        const bool more = kc + 1 < nK;
+        if (more) gload(kc + 1);
+        const float* Ab = &As[(cur * BM + wm * 64 + li) * KC_PITCH + lh * 4];
+        const float* Bb = &Bs[(cur * BN + wn * (BN / 2) + li) * KC_PITCH + lh * 4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float af[2][4], bf[NB][4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                *reinterpret_cast<float4*>(af[mb]) =
+                    *reinterpret_cast<const float4*>(Ab + mb * 32 * KC_PITCH + g * 8);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                *reinterpret_cast<float4*>(bf[nb]) =
+                    *reinterpret_cast<const float4*>(Bb + nb * 32 * KC_PITCH + g * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = mfma32(af[mb][j], bf[nb][j], acc[mb][nb]);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = n0 + wn * (BN / 2) + nb * 32 + li;
+        const bool cok = col < a.Cout;
+        const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < a.M) a.y[(size_t)row * a.ldy + col] = acc[mb][nb][r] + bv;
+            }
+        }
+    }
+    if (a.stats != nullptr) {
+        // rows past M were staged as zeros, so they add nothing to either sum
+        float* red = smem;  // [2 (sum, sumsq)][2 (wm)][BN]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mb][nb][r];
+                    s += v;
+                    s2 += v * v;
+                }
+            s += __shfl_xor(s, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0) {
+                int c = wn * (BN / 2) + nb * 32 + li;
+                red[(0 * 2 + wm) * BN + c] = s;
+                red[(1 * 2 + wm) * BN + c] = s2;
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < a.Cout) {
+            float s = red[(0 * 2 + 0) * BN + t] + red[(0 * 2 + 1) * BN + t];
+            float s2 = red[(1 * 2 + 0) * BN + t] + red[(1 * 2 + 1) * BN + t];
+            a.stats[(size_t)mt * a.Cout + n0 + t] = s;
+            a.stats[(size_t)(a.MT + mt) * a.Cout + n0 + t] = s2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dgrad:  dx[m, ci] = sum_k dyG[m, k] * W[k, ci],  m = (n, ih, iw),  k = (kh, kw, co)
+// A: gather from dy (K-contiguous).  B: OHWI weights read with ci contiguous (row-contiguous).
+// ------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv_dgrad(const ConvArgs a) {
+    constexpr int BM = 128;
+    constexpr int NB = BN / 64;
+    constexpr int BQ = BN / 4;         // float4 columns of the B tile
+    constexpr int BKR = 256 / BQ;      // k rows covered per pass
+    constexpr int BPASS = 32 / BKR;    // passes per thread
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * KC_PITCH + 2 * 32 * BN];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * KC_PITCH;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L / a.NT, nt = L - mt * a.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int q = t & 7, r0 = t >> 3;
+    const int bq = t % BQ, bk0 = t / BQ;
+
+    // rows are INPUT pixels here: a.H/a.W input dims, a.Ho/a.Wo the dims of dy
+    const int HW = a.H * a.W;
+    int thb[4], twb[4], pb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int m = m0 + r0 + 32 * j;
+        if (m < a.M) {
+            int n = m / HW, rem = m - n * HW;
+            int ih = rem / a.W, iw = rem - ih * a.W;
+            thb[j] = ih + a.pad;
+            twb[j] = iw + a.pad;
+            pb[j] = n * a.Ho * a.Wo;
+        } else {
+            thb[j] = -(1 << 28);
+            twb[j] = 0;
+            pb[j] = 0;
+        }
+    }
+    const int Co4 = a.Cout >> 2, K4 = a.Ktot >> 2;
+    const int taps = a.KH * a.KW;
+    const bool nok = n0 + bq * 4 < a.Cin;
+
+    float4 ra[4], rb[BPASS];
+    auto gload = [&](int kc) {
+        const int k4 = kc * 8 + q;
+        const bool kv = k4 < K4;
+        const int tap = k4 / Co4, c4 = k4 - tap * Co4;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int dh = kh * a.dil, dw = kw * a.dil;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int th = thb[j] - dh, tw = twb[j] - dw;
+            int oh = th, ow = tw;
+            bool ok = kv && th >= 0 && tw >= 0;
+            if (a.stride != 1) {
+                oh = th / a.stride;
+                ow = tw / a.stride;
+                ok = ok && (oh * a.stride == th) && (ow * a.stride == tw);
+            }
+            ok = ok && oh < a.Ho && ow < a.Wo;
+            ra[j] = ok ? ldg4(a.x + (size_t)(pb[j] + oh * a.Wo + ow) * a.ldx + c4 * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            int k = kc * 32 + bk0 + BKR * j;
+            bool ok = nok && k < a.Ktot;
+            int tp = k / a.Cout, co = k - tp * a.Cout;
+            rb[j] = ok ? ldg4(a.w + ((size_t)co * taps + tp) * a.Cin + n0 + bq * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(&As[(buf * BM + r0 + 32 * j) * KC_PITCH + q * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j)
+            *reinterpret_cast<float4*>(&Bs[(buf * 32 + bk0 + BKR * j) * BN + bq * 4]) = rb[j];
+    };
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nK = (a.Ktot + 31) >> 5;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nK; ++kc) {
+        const int cur = kc & 1;
+        const bool more = kc + 1 < nK;
+        if (more) gload(kc + 1);
+        const float* Ab = &As[(cur * BM + wm * 64 + li) * KC_PITCH + lh * 4];
+        const float* Bb = &Bs[(cur * 32 + lh * 4) * BN + wn * (BN / 2) + li];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float af[2][4], bf[NB][4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                *reinterpret_cast<float4*>(af[mb]) =
+                    *reinterpret_cast<const float4*>(Ab + mb * 32 * KC_PITCH + g * 8);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[nb][j] = Bb[(g * 8 + j) * BN + nb * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = mfma32(af[mb][j], bf[nb][j], acc[mb][nb]);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = n0 + wn * (BN / 2) + nb * 32 + li;
+        const bool cok = col < a.Cin;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < a.M) {
+                    float* o = &a.y[(size_t)row * a.ldy + col];
+                    *o = a.accumulate ? *o + acc[mb][nb][r] : acc[mb][nb][r];
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad:  dw[co, j] = sum_p dy[p, co] * xG[p, j],  j = (kh, kw, ci) flattened, p = (n, oh, ow)
+// Both operands row-contiguous; the pixel axis is split across blockIdx.y into slabs.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
+    constexpr int MB = BM / 64, NB = BN / 64;
+    constexpr int AQ = BM / 4, AKR = 256 / AQ, APASS = 32 / AKR;
+    constexpr int BQ = BN / 4, BKR = 256 / BQ, BPASS = 32 / BKR;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * (BM + BN)];
+    float* As = smem;
+    float* Bs = smem + 2 * 32 * BM;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L / a.NT, nt = L - mt * a.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int split = blockIdx.y;
+    const int P = a.M;  // pixels of dy
+    const int p_begin = split * a.psplit;
+    const int p_end = min(P, p_begin + a.psplit);
+
+    const int aq = t % AQ, ak0 = t / AQ;
+    const int bq = t % BQ, bk0 = t / BQ;
+    const bool aok = m0 + aq * 4 < a.Cout;
+
+    // this thread's B column: one (tap, ci4) for the whole K loop
+    const int Cin4 = a.Cin >> 2;
+    const int n4 = (n0 >> 2) + bq;
+    const bool bok = n4 < (a.Ktot >> 2);
+    const int tap = n4 / Cin4, c4 = n4 - tap * Cin4;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int dh = kh * a.dil - a.pad, dw = kw * a.dil - a.pad;
+
+    // pixel coordinates of this thread's B rows, advanced by 32 pixels per chunk
+    int bn_[BPASS], boh[BPASS], bow[BPASS];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+        int p = p_begin + bk0 + BKR * j;
+        int n = p / HoWo, rem = p - n * HoWo;
+        bn_[j] = n;
+        boh[j] = rem / a.Wo;
+        bow[j] = rem - boh[j] * a.Wo;
+    }
+
+    float4 ra[APASS], rb[BPASS];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            int p = p_begin + kc * 32 + ak0 + AKR * j;
+            ra[j] = (aok && p < p_end) ? ldg4(a.y + (size_t)p * a.ldy + m0 + aq * 4)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            int p = p_begin + kc * 32 + bk0 + BKR * j;
+            int ih = boh[j] * a.stride + dh, iw = bow[j] * a.stride + dw;
+            bool ok = bok && p < p_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            rb[j] = ok ? ldg4(a.x + (size_t)((bn_[j] * a.H + ih) * a.W + iw) * a.ldx + c4 * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            // advance to the next chunk's pixel
+            bow[j] += 32;
+            while (bow[j] >= a.Wo) {
+                bow[j] -= a.Wo;
+                boh[j] += 1;
+            }
+            while (boh[j] >= a.Ho) {
+                boh[j] -= a.Ho;
+                bn_[j] += 1;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j)
+            *reinterpret_cast<float4*>(&As[(buf * 32 + ak0 + AKR * j) * BM + aq * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j)
+            *reinterpret_cast<float4*>(&Bs[(buf * 32 + bk0 + BKR * j) * BN + bq * 4]) = rb[j];
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nK = (p_end - p_begin + 31) >> 5;
+    if (nK > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kc = 0; kc < nK; ++kc) {
+        const int cur = kc & 1;
+        const bool more = kc + 1 < nK;
+        if (more) gload(kc + 1);
+        const float* Ab = &As[(cur * 32 + lh * 4) * BM + wm * (BM / 2) + li];
+        const float* Bb = &Bs[(cur * 32 + lh * 4) * BN + wn * (BN / 2) + li];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float af[MB][4], bf[NB][4];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[mb][j] = Ab[(g * 8 + j) * BM + mb * 32];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[nb][j] = Bb[(g * 8 + j) * BN + nb * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = mfma32(af[mb][j], bf[nb][j], acc[mb][nb]);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    float* out = a.stats + (size_t)split * a.Cout * a.Ktot;  // slab (or dw itself when nsplit == 1)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = n0 + wn * (BN / 2) + nb * 32 + li;
+        const bool cok = col < a.Ktot;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < a.Cout) out[(size_t)row * a.Ktot + col] = acc[mb][nb][r];
+            }
+    }
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ dst, int64_t n4,
+                               int nsplit) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<const float4*>(slabs)[i];
+        for (int k = 1; k < nsplit; ++k) {
+            float4 v = reinterpret_cast<const float4*>(slabs)[i + (int64_t)k * n4];
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        reinterpret_cast<float4*>(dst)[i] = s;
+    }
+}
+
+static int validate(const iswm_conv_desc* d) {
+    ISWM_REQUIRE(d != nullptr, "conv: null descriptor");
+    ISWM_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: empty tensor");
+    ISWM_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "conv: Cin (%d) and Cout (%d) must be multiples of 4",
+                 d->Cin, d->Cout);
+    ISWM_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout,
+                 "conv: bad pixel pitch ldx=%d ldy=%d", d->ldx, d->ldy);
+    ISWM_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "conv: bad geometry");
+    int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+    int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+    ISWM_REQUIRE(ho == d->Ho && wo == d->Wo, "conv: output size %dx%d does not match geometry (%dx%d)", d->Ho,
+                 d->Wo, ho, wo);
+    ISWM_REQUIRE((int64_t)d->N * d->H * d->W * d->ldx < (1ll << 31) &&
+                     (int64_t)d->N * d->Ho * d->Wo * d->ldy < (1ll << 31),
+                 "conv: tensor exceeds 2^31 elements");
+    return 0;
+}
+
+static ConvArgs base_args(const iswm_conv_desc* d) {
+    ConvArgs a{};
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.ldx = d->ldx; a.ldy = d->ldy;
+    return a;
+}
+
+struct WgradPlan {
+    int bm, bn, MT, NT, nsplit, psplit;
+};
+
+static WgradPlan plan_wgrad(const iswm_conv_desc* d) {
+    WgradPlan p;
+    const int Ktot = d->KH * d->KW * d->Cin;
+    p.bm = (d->Cout % 128 == 0) ? 128 : 64;
+    p.bn = (p.bm == 128 && (Ktot % 128 == 0 || Ktot >= 1024)) ? 128 : 64;
+    if (p.bn == 64) p.bm = 64;  // instantiated shapes: 128x128 and 64x64
+    p.MT = (d->Cout + p.bm - 1) / p.bm;
+    p.NT = (Ktot + p.bn - 1) / p.bn;
+    const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+    const int64_t tiles = (int64_t)p.MT * p.NT;
+    int64_t want = (1024 + tiles - 1) / tiles;         // ~4 workgroups per CU in total
+    int64_t maxs = (P + 255) / 256;                    // at least 256 pixels per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    int64_t ps = (P + want - 1) / want;
+    ps = (ps + 31) / 32 * 32;
+    p.psplit = (int)ps;
+    p.nsplit = (int)((P + ps - 1) / ps);
+    return p;
+}
+
+}  // namespace iswm
+
+using namespace iswm;
+
+extern "C" int iswm_conv2d_stat_tiles(const iswm_conv_desc* d) {
+    if (!d) return 0;
+    int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    return (int)((M + 127) / 128);
+}
+
+extern "C" int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const float* w, const float* bias,
+                               float* y, float* stat_partials, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(x && w && y, "conv_fwd: null pointer");
+    ISWM_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "conv_fwd: pointers must be 16-byte aligned");
+    ConvArgs a = base_args(d);
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stat_partials;
+    a.M = d->N * d->Ho * d->Wo;
+    a.Ktot = d->KH * d->KW * d->Cin;
+    a.MT = (a.M + 127) / 128;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout % 128 <= 64)) {
+        a.NT = (d->Cout + 63) / 64;
+        hipLaunchKernelGGL(k_conv_fwd<64>, dim3(a.MT * a.NT), dim3(256), 0, s, a);
+    } else {
+        a.NT = (d->Cout + 127) / 128;
+        hipLaunchKernelGGL(k_conv_fwd<128>, dim3(a.MT * a.NT), dim3(256), 0, s, a);
+    }
+    return check_launch("conv_fwd");
+}
+
+extern "C" int iswm_conv2d_dgrad(const iswm_conv_desc* d, const float* dy, const float* w, float* dx,
+                                 int accumulate, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(dy && w && dx, "conv_dgrad: null pointer");
+    ISWM_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx), "conv_dgrad: pointers must be 16-byte aligned");
+    ConvArgs a = base_args(d);
+    // kernel naming: a.x = gathered operand (dy, pitch ldy), a.y = output (dx, pitch ldx)
+    a.x = dy; a.w = w; a.y = dx; a.accumulate = accumulate;
+    a.ldx = d->ldy; a.ldy = d->ldx;
+    a.M = d->N * d->H * d->W;
+    a.Ktot = d->KH * d->KW * d->Cout;
+    a.MT = (a.M + 127) / 128;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cin <= 64 || (d->Cin % 128 != 0 && d->Cin % 128 <= 64)) {
+        a.NT = (d->Cin + 63) / 64;
+        hipLaunchKernelGGL(k_conv_dgrad<64>, dim3(a.MT * a.NT), dim3(256), 0, s, a);
+    } else {
+        a.NT = (d->Cin + 127) / 128;
+        hipLaunchKernelGGL(k_conv_dgrad<128>, dim3(a.MT * a.NT), dim3(256), 0, s, a);
+    }
+    return check_launch("conv_dgrad");
+}
+
+extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {
+    if (!d) return 0;
+    WgradPlan p = plan_wgrad(d);
+    if (p.nsplit <= 1) return 0;
+    return (size_t)p.nsplit * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+}
+
+extern "C" int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const float* dy, float* dw,
+                                 float* workspace, size_t workspace_bytes, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
+    ISWM_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw), "conv_wgrad: pointers must be 16-byte aligned");
+    WgradPlan p = plan_wgrad(d);
+    const size_t need = iswm_conv2d_wgrad_workspace(d);
+    ISWM_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))),
+                 "conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    ConvArgs a = base_args(d);
+    a.x = x; a.y = const_cast<float*>(dy);
+    a.M = d->N * d->Ho * d->Wo;
+    a.Ktot = d->KH * d->KW * d->Cin;
+    a.MT = p.MT; a.NT = p.NT; a.nsplit = p.nsplit; a.psplit = p.psplit;
+    a.stats = (p.nsplit > 1) ? workspace : dw;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p.MT * p.NT, p.nsplit);
+    if (p.bm == 128)
+        hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, s, a);
+    if (int e = check_launch("conv_wgrad")) return e;
+    if (p.nsplit > 1) {
+        int64_t n4 = (int64_t)d->Cout * a.Ktot / 4;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(stream_grid(n4, 256)), dim3(256), 0, s, workspace, dw, n4,
+                           p.nsplit);
+        return check_launch("conv_wgrad_reduce");
+    }
+    return 0;
+}

@@ -1,0 +1,356 @@
+"""Execution layer of the HIP backend: modules with a hand-written forward AND
+backward over NHWC activations.
+
+The reference is a tree of stock ``torch.nn`` modules driven by autograd
+(network/utils.py:16-25).  Here every module keeps the reference's name, children
+and parameters (so ``state_dict`` keys match) but implements
+
+    fwd(x, save)  -> y          NHWC in, NHWC out; ``save`` keeps what bwd needs
+    bwd(dy, sink) -> dx         hand-written backward; parameter gradients are
+                                written straight into ``p.grad`` via ``sink``
+
+and the whole model is ONE node in torch's autograd graph (``_Bridge``), so
+``loss.backward()`` / ``optimizer.step()`` in train.py work unchanged while no
+torch op ever touches an activation.  All compute is libiswm_hip.so kernels.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def dense_flat(t):
+    """1-D view over the dense memory of a parameter-shaped tensor (contiguous or
+    channels_last)."""
+    if t.dim() == 4 and not t.is_contiguous():
+        v = t.permute(0, 2, 3, 1)
+        assert v.is_contiguous(), "parameter is neither contiguous nor channels_last"
+        return v.reshape(-1)
+    assert t.is_contiguous()
+    return t.reshape(-1)
+
+
+class GradSink:
+    """Where parameter gradients go.  ``target(p)`` returns a tensor shaped/strided
+    like ``p`` for a kernel to overwrite; ``done(p)`` folds it into ``p.grad``
+    (a no-op on the usual zero_grad(set_to_none=True) path) and fires the
+    data-parallel ready hook."""
+
+    def __init__(self, on_ready=None):
+        self.on_ready = on_ready
+        self._pending = {}
+
+    def target(self, p):
+        if p.grad is None:
+            view = getattr(p, "_iswm_grad_view", None)
+            p.grad = view if view is not None else torch.empty_like(p)
+            return p.grad
+        tmp = torch.empty_like(p)
+        self._pending[id(p)] = tmp
+        return tmp
+
+    def done(self, p):
+        tmp = self._pending.pop(id(p), None)
+        if tmp is not None:
+            ops.add_inplace(dense_flat(p.grad), dense_flat(tmp))
+        if self.on_ready is not None:
+            self.on_ready(p)
+
+
+class HipModule(nn.Module):
+    """Base: public ``forward`` takes/returns NCHW like the reference module and
+    bridges to fwd/bwd."""
+
+    def fwd(self, x, save):
+        raise NotImplementedError
+
+    def bwd(self, dy, sink):
+        raise NotImplementedError
+
+    def out_channels_of(self, cin):
+        """logical channel count of the output (to strip channel padding)."""
+        return None
+
+    def forward(self, x):
+        return run_module(self, x)
+
+
+class _Bridge(torch.autograd.Function):
+    """One autograd node for a whole HipModule call (NCHW tensors outside)."""
+
+    @staticmethod
+    def forward(ctx, mod, cout, x, *params):
+        xh = ops.nchw_to_nhwc(x)
+        yh = mod.fwd(xh, True)
+        ctx.mod, ctx.cin, ctx.need_dx = mod, x.shape[1], x.requires_grad
+        return ops.nhwc_to_nchw(yh, cout or yh.shape[3])
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod = ctx.mod
+        dyh = ops.nchw_to_nhwc(dy.contiguous())
+        sink = GradSink(getattr(mod, "_iswm_on_ready", None))
+        dxh = mod.bwd(dyh, sink)
+        dx = ops.nhwc_to_nchw(dxh, ctx.cin) if (ctx.need_dx and dxh is not None) else None
+        return (None, None, dx) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def run_module(mod, x):
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        raise ValueError("iswm_amd modules take a 4-D fp32 CUDA NCHW tensor (no CPU fallback); got %s" %
+                         (x.shape if torch.is_tensor(x) else type(x),))
+    params = [p for p in mod.parameters() if p.requires_grad]
+    cout = mod.out_channels_of(x.shape[1])
+    if torch.is_grad_enabled() and (x.requires_grad or params):
+        return _Bridge.apply(mod, cout, x, *params)
+    yh = mod.fwd(ops.nchw_to_nhwc(x), False)
+    return ops.nhwc_to_nchw(yh, cout or yh.shape[3])
+
+
+# ---------------------------------------------------------------------------------------
+# leaf modules: same classes/keys as torch.nn so isinstance checks in the reference's
+# _init_weight (network/_deeplab.py:63-69) and state_dict round-trips keep working
+# ---------------------------------------------------------------------------------------
+class Conv2d(HipModule, nn.Conv2d):
+    """nn.Conv2d(groups=1) whose weight lives in channels_last memory format, i.e.
+    physically OHWI -- the layout the implicit-GEMM kernels read directly."""
+
+    def __init__(self, *args, **kwargs):
+        nn.Conv2d.__init__(self, *args, **kwargs)
+        if self.groups != 1 or self.padding_mode != "zeros":
+            raise NotImplementedError("HIP conv supports groups=1, zero padding")
+        if self.kernel_size[0] != self.kernel_size[1] or self.dilation[0] != self.dilation[1] or \
+                self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError("HIP conv supports square kernels/strides/dilations")
+        with torch.no_grad():
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        self._saved = None
+
+    # -- operand views -----------------------------------------------------------------
+    @property
+    def cin_p(self):
+        return pad4(self.in_channels)
+
+    @property
+    def cout_p(self):
+        return pad4(self.out_channels)
+
+    def needs_pack(self):
+        return self.cin_p != self.in_channels or self.cout_p != self.out_channels
+
+    def ohwi(self):
+        """OHWI weight for the kernels; zero-padded copy when Cin/Cout % 4 != 0
+        (the 3-channel stem, the num_classes-wide classifier)."""
+        w = self.weight
+        v = w.permute(0, 2, 3, 1)
+        if not self.needs_pack():
+            return v if v.is_contiguous() else v.contiguous()
+        k = self.kernel_size[0]
+        wp = torch.zeros((self.cout_p, k, k, self.cin_p), dtype=w.dtype, device=w.device)
+        wp[:self.out_channels, :, :, :self.in_channels] = v
+        return wp
+
+    def bias_p(self):
+        if self.bias is None:
+            return None
+        if self.cout_p == self.out_channels:
+            return self.bias
+        b = torch.zeros((self.cout_p,), dtype=self.bias.dtype, device=self.bias.device)
+        b[:self.out_channels] = self.bias
+        return b
+
+    def geometry(self, x):
+        if x.shape[3] != self.cin_p:
+            raise ValueError("conv expects %d (padded) input channels, got %d" % (self.cin_p, x.shape[3]))
+        return ops.ConvGeom(x, self.cout_p, self.kernel_size[0], self.kernel_size[1], self.stride[0],
+                            self.padding[0], self.dilation[0])
+
+    def write_wgrad(self, x, dy, g, sink):
+        """weight gradient straight into p.grad's memory when it is OHWI-dense."""
+        p = self.weight
+        if not p.requires_grad:
+            return
+        buf = sink.target(p)
+        v = buf.permute(0, 2, 3, 1)
+        if not self.needs_pack() and v.is_contiguous():
+            ops.conv2d_wgrad(x, dy, g, v)
+        else:
+            dw = ops.conv2d_wgrad(x, dy, g)
+            buf.copy_(dw[:self.out_channels, :, :, :self.in_channels].permute(0, 3, 1, 2))
+        sink.done(p)
+
+    # -- standalone conv (+bias), e.g. the final 1x1 classifier ---------------------------
+    def fwd(self, x, save, out=None):
+        g = self.geometry(x)
+        y, _, _ = ops.conv2d_fwd(x, self.ohwi(), g, bias=self.bias_p(), out=out)
+        self._saved = (x, g) if save else None
+        return y
+
+    def bwd(self, dy, sink, need_dx=True, dx=None, accumulate=False):
+        x, g = self._saved
+        self._saved = None
+        if self.bias is not None and self.bias.requires_grad:
+            partials, tiles = ops.colstat(dy)
+            c = dy.shape[3]
+            tmp = torch.empty((2, c), dtype=torch.float32, device=dy.device)
+            ops.call("iswm_bn_bwd_finalize", ops._p(partials), tiles, c, ops._p(tmp[1]), ops._p(tmp[0]),
+                     ops._stream())
+            sink.target(self.bias).copy_(tmp[0, :self.out_channels])
+            sink.done(self.bias)
+        self.write_wgrad(x, dy, g, sink)
+        if not need_dx:
+            return None
+        return ops.conv2d_dgrad(dy, self.ohwi(), g, tuple(x.shape), dx, accumulate)
+
+    def out_channels_of(self, cin):
+        return self.out_channels
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    pass
+
+
+class ReLU(nn.ReLU):
+    pass
+
+
+class Dropout(HipModule, nn.Dropout):
+    """nn.Dropout(p) (network/_deeplab.py:165) with a Philox counter mask."""
+
+    def __init__(self, *a, **k):
+        nn.Dropout.__init__(self, *a, **k)
+        self._calls = 0
+        self._mask = None
+
+    def fwd(self, x, save):
+        if not self.training or self.p == 0.0:
+            self._mask = None
+            return x
+        self._calls += 1
+        y, mask = ops.dropout_fwd(x, self.p, torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, self._calls)
+        self._mask = mask if save else None
+        return y
+
+    def bwd(self, dy, sink):
+        if self._mask is None:
+            return dy
+        dx = ops.dropout_bwd(dy.contiguous(), self._mask, self.p)
+        self._mask = None
+        return dx
+
+
+# ---------------------------------------------------------------------------------------
+# conv -> BatchNorm -> (+residual) -> ReLU, the unit every stage of the net is made of
+# ---------------------------------------------------------------------------------------
+def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
+    """Returns (out, ctx).  Training-mode BN statistics come from the conv epilogue's
+    per-tile partial sums (no extra pass over y)."""
+    g = conv.geometry(x)
+    training = bn.training
+    if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+        raise NotImplementedError("HIP BatchNorm2d supports affine=True, momentum!=None, running stats")
+    y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training)
+    if training:
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        if count <= 1:
+            # same contract as torch (network/_deeplab.py:130-141 needs batch >= 2)
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" %
+                             (tuple(y.shape),))
+        coef = ops.bn_finalize(partials, tiles, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               bn.momentum, bn.eps)
+        bn.num_batches_tracked.add_(1)
+    else:
+        coef = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    o = ops.bn_apply(y, coef, relu, residual, out)
+    ctx = None
+    if save:
+        ctx = dict(x=x, y=y, out=o, coef=coef, g=g, relu=relu, training=training, res=residual is not None)
+    return o, ctx
+
+
+def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
+    """Returns (dx, dres): dres is the gradient of the residual input (if any)."""
+    x, y, o, g = ctx["x"], ctx["y"], ctx["out"], ctx["g"]
+    gw, gb = bn.weight, bn.bias
+    dgamma = sink.target(gw) if gw.requires_grad else torch.empty_like(gw)
+    dbeta = sink.target(gb) if gb.requires_grad else torch.empty_like(gb)
+    dy, dres = ops.bn_backward(dout, o if ctx["relu"] else None, y, ctx["coef"], gw, ctx["relu"], ctx["training"],
+                               dgamma, dbeta, want_dres=ctx["res"])
+    if gw.requires_grad:
+        sink.done(gw)
+    if gb.requires_grad:
+        sink.done(gb)
+    conv.write_wgrad(x, dy, g, sink)
+    if need_dx:
+        dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate)
+    else:
+        dx = None
+    return dx, dres
+
+
+class HipSequential(HipModule, nn.Sequential):
+    """nn.Sequential whose children are grouped into fused stages:
+    [Conv2d, BatchNorm2d, ReLU?] -> cba;  Conv2d alone -> conv(+bias);  Dropout;  HipModule."""
+
+    def _stages(self):
+        mods = list(self.children())
+        st, i = [], 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Conv2d):
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+                    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                    st.append(("cba", m, mods[i + 1], relu))
+                    i += 3 if relu else 2
+                else:
+                    st.append(("conv", m))
+                    i += 1
+            elif isinstance(m, HipModule):
+                st.append(("mod", m))
+                i += 1
+            else:
+                raise NotImplementedError("no HIP implementation for %s inside a Sequential" % type(m).__name__)
+        return st
+
+    def fwd(self, x, save, out=None):
+        st = self._stages()
+        ctxs = []
+        for k, s in enumerate(st):
+            last = k == len(st) - 1
+            if s[0] == "cba":
+                x, c = cba_fwd(s[1], s[2], s[3], x, save, out=out if last else None)
+                ctxs.append(c)
+            elif s[0] == "conv":
+                x = s[1].fwd(x, save, out=out if last else None)
+                ctxs.append(None)
+            else:
+                x = s[1].fwd(x, save)
+                ctxs.append(None)
+        self._saved = (st, ctxs) if save else None
+        return x
+
+    def bwd(self, dy, sink, need_dx=True, dx=None, accumulate=False):
+        st, ctxs = self._saved
+        self._saved = None
+        for k in range(len(st) - 1, -1, -1):
+            s = st[k]
+            first = k == 0
+            if s[0] == "cba":
+                dy, _ = cba_bwd(s[1], s[2], ctxs[k], dy, sink, need_dx or not first, dx if first else None,
+                                accumulate and first)
+            elif s[0] == "conv":
+                dy = s[1].bwd(dy, sink, need_dx or not first, dx if first else None, accumulate and first)
+            else:
+                dy = s[1].bwd(dy, sink)
+        return dy
+
+    def out_channels_of(self, cin):
+        c = None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                c = m.out_channels
+        return c

@@ -1,0 +1,350 @@
+"""Tensor-level wrappers over the C ABI (include/iswm_hip.h).
+
+torch supplies device memory, the current HIP stream and nothing else: every
+function here validates its tensors, allocates outputs through torch's caching
+allocator and enqueues hand-written gfx950 kernels from libiswm_hip.so on
+``torch.cuda.current_stream()``.  There is no fallback path.
+
+Activations are NHWC: a 4-D fp32 tensor ``[N, H, W, C]`` whose last dim is
+contiguous and whose pixel pitch ``ld = t.stride(2)`` may exceed C (a channel
+slice of a wider buffer -- that is how torch.cat disappears from the graph).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call
+
+BN_EPS = 1e-5
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def geom(t):
+    """(N, H, W, C, ld) of an NHWC activation view; raises on any other layout."""
+    if t.dim() != 4 or t.dtype != torch.float32 or not t.is_cuda:
+        raise ValueError("expected a 4-D fp32 CUDA NHWC tensor, got %s %s %s" % (tuple(t.shape), t.dtype, t.device))
+    n, h, w, c = t.shape
+    if w > 1:
+        ld = t.stride(2)
+    elif h > 1:
+        ld = t.stride(1)
+    elif n > 1:
+        ld = t.stride(0)
+    else:
+        ld = c
+    ok = (c == 1 or t.stride(3) == 1) and (w == 1 or t.stride(2) == ld) and \
+        (h == 1 or t.stride(1) == w * ld) and (n == 1 or t.stride(0) == h * w * ld)
+    if not ok or ld < c:
+        raise ValueError("tensor is not a pitched NHWC view: shape %s strides %s" % (tuple(t.shape), t.stride()))
+    return n, h, w, c, ld
+
+
+def new_act(n, h, w, c, device):
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=device)
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+class ConvGeom:
+    """Static geometry of one conv call (wraps iswm_conv_desc)."""
+
+    def __init__(self, x, cout, kh, kw, stride, pad, dil):
+        n, h, w, cin, ldx = geom(x)
+        self.n, self.h, self.w, self.cin, self.cout = n, h, w, cin, cout
+        self.kh, self.kw, self.stride, self.pad, self.dil = kh, kw, stride, pad, dil
+        self.ho = conv_out_size(h, kh, stride, pad, dil)
+        self.wo = conv_out_size(w, kw, stride, pad, dil)
+
+    def desc(self, ldx, ldy):
+        return ConvDesc(self.n, self.h, self.w, self.cin, self.ho, self.wo, self.cout, self.kh, self.kw,
+                        self.stride, self.pad, self.dil, ldx, ldy)
+
+
+def _check_w(w_ohwi, g):
+    if tuple(w_ohwi.shape) != (g.cout, g.kh, g.kw, g.cin) or not w_ohwi.is_contiguous():
+        raise ValueError("weight must be contiguous OHWI %s, got %s strides %s" %
+                         ((g.cout, g.kh, g.kw, g.cin), tuple(w_ohwi.shape), w_ohwi.stride()))
+
+
+def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
+    """y = conv(x, w) [+ bias]; returns (y, partials|None, tiles)."""
+    ldx = geom(x)[4]
+    _check_w(w_ohwi, g)
+    if out is None:
+        out = new_act(g.n, g.ho, g.wo, g.cout, x.device)
+    on, oh, ow, oc, ldy = geom(out)
+    assert (on, oh, ow, oc) == (g.n, g.ho, g.wo, g.cout)
+    d = g.desc(ldx, ldy)
+    partials, tiles = None, 0
+    if want_stats:
+        tiles = _lib.load().iswm_conv2d_stat_tiles(ctypes.byref(d))
+        partials = torch.empty((2, tiles, g.cout), dtype=torch.float32, device=x.device)
+    call("iswm_conv2d_fwd", ctypes.byref(d), _p(x), _p(w_ohwi), _p(bias), _p(out), _p(partials), _stream())
+    return out, partials, tiles
+
+
+def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
+    """dx (=|+=) conv^T(dy, w).  x_like_shape = (N,H,W,Cin) of the conv input."""
+    ldy = geom(dy)[4]
+    _check_w(w_ohwi, g)
+    if dx is None:
+        assert not accumulate
+        dx = new_act(*x_like_shape, dy.device)
+    ldx = geom(dx)[4]
+    d = g.desc(ldx, ldy)
+    call("iswm_conv2d_dgrad", ctypes.byref(d), _p(dy), _p(w_ohwi), _p(dx), int(bool(accumulate)), _stream())
+    return dx
+
+
+def conv2d_wgrad(x, dy, g, dw_ohwi=None):
+    """dw[Cout,KH,KW,Cin] = sum_pixels dy (x) gathered x."""
+    ldx, ldy = geom(x)[4], geom(dy)[4]
+    if dw_ohwi is None:
+        dw_ohwi = torch.empty((g.cout, g.kh, g.kw, g.cin), dtype=torch.float32, device=x.device)
+    _check_w(dw_ohwi, g)
+    d = g.desc(ldx, ldy)
+    need = _lib.load().iswm_conv2d_wgrad_workspace(ctypes.byref(d))
+    ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device) if need else None
+    call("iswm_conv2d_wgrad", ctypes.byref(d), _p(x), _p(dy), _p(dw_ohwi), _p(ws), need, _stream())
+    return dw_ohwi
+
+
+def rows(t):
+    n, h, w, c, ld = geom(t)
+    return n * h * w, c, ld
+
+
+def colstat(x):
+    m, c, ld = rows(x)
+    tiles = _lib.load().iswm_colstat_tiles(m)
+    partials = torch.empty((2, tiles, c), dtype=torch.float32, device=x.device)
+    call("iswm_colstat", _p(x), m, c, ld, _p(partials), _stream())
+    return partials, tiles
+
+
+def bn_finalize(partials, tiles, count, gamma, beta, running_mean, running_var, momentum, eps=BN_EPS):
+    c = partials.shape[2]
+    coef = torch.empty((4, c), dtype=torch.float32, device=partials.device)  # scale, shift, mean, invstd
+    call("iswm_bn_finalize", _p(partials), tiles, c, count, _p(gamma), _p(beta), _p(running_mean),
+         _p(running_var), float(momentum), float(eps), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream())
+    return coef
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
+    c = running_mean.numel()
+    coef = torch.empty((4, c), dtype=torch.float32, device=running_mean.device)
+    call("iswm_bn_eval_coeffs", c, _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), _p(coef[0]),
+         _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream())
+    return coef
+
+
+def bn_apply(y, coef, relu, residual=None, out=None):
+    m, c, ldy = rows(y)
+    if out is None:
+        out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    mo, co, ldo = rows(out)
+    assert (mo, co) == (m, c)
+    ldr = 0
+    if residual is not None:
+        mr, cr, ldr = rows(residual)
+        assert (mr, cr) == (m, c)
+    call("iswm_bn_apply", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(residual), ldr, int(bool(relu)), _p(out),
+         ldo, _stream())
+    return out
+
+
+def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_dres=False, dy=None):
+    """Returns (dy, dres|None); writes dgamma / dbeta (length-C fp32 tensors)."""
+    m, c, ldy = rows(y)
+    _, _, ldd = rows(dout)
+    ldo = rows(out)[2] if out is not None else 0
+    tiles = _lib.load().iswm_colstat_tiles(m)
+    partials = torch.empty((2, tiles, c), dtype=torch.float32, device=y.device)
+    call("iswm_bn_bwd_reduce", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]),
+         int(bool(relu)), _p(partials), _stream())
+    call("iswm_bn_bwd_finalize", _p(partials), tiles, c, _p(dgamma), _p(dbeta), _stream())
+    if dy is None:
+        dy = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    dres = torch.empty(y.shape, dtype=torch.float32, device=y.device) if want_dres else None
+    call("iswm_bn_bwd_apply", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
+         _p(dgamma), _p(dbeta), int(bool(relu)), int(bool(training)), _p(dy), rows(dy)[2], _p(dres),
+         rows(dres)[2] if dres is not None else 0, _stream())
+    return dy, dres
+
+
+def maxpool_fwd(x):
+    n, h, w, c, ld = geom(x)
+    assert ld == c
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = new_act(n, ho, wo, c, x.device)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    call("iswm_maxpool3x3s2_fwd", _p(x), n, h, w, c, _p(y), _p(idx), ho, wo, _stream())
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape):
+    n, h, w, c = in_shape
+    _, ho, wo, _, ld = geom(dy)
+    assert ld == c
+    dx = new_act(n, h, w, c, dy.device)
+    call("iswm_maxpool3x3s2_bwd", _p(dy), _p(idx), n, h, w, c, ho, wo, _p(dx), _stream())
+    return dx
+
+
+def gap_fwd(x):
+    n, h, w, c, ld = geom(x)
+    y = new_act(n, 1, 1, c, x.device)
+    call("iswm_gap_fwd", _p(x), n, h * w, c, ld, _p(y), _stream())
+    return y
+
+
+def gap_bwd(dy, dx, accumulate):
+    n, h, w, c, ld = geom(dx)
+    call("iswm_gap_bwd", _p(dy), n, h * w, c, _p(dx), ld, int(bool(accumulate)), _stream())
+    return dx
+
+
+def bcast_fwd(v, out):
+    n, h, w, c, ld = geom(out)
+    call("iswm_bcast_fwd", _p(v), n, h * w, c, _p(out), ld, _stream())
+    return out
+
+
+def bcast_bwd(dy):
+    n, h, w, c, ld = geom(dy)
+    dv = new_act(n, 1, 1, c, dy.device)
+    call("iswm_bcast_bwd", _p(dy), ld, n, h * w, c, _p(dv), _stream())
+    return dv
+
+
+def bilinear_fwd(x, ho, wo, out=None):
+    n, hi, wi, c, ldx = geom(x)
+    if out is None:
+        out = new_act(n, ho, wo, c, x.device)
+    ldy = geom(out)[4]
+    call("iswm_bilinear_fwd", _p(x), n, hi, wi, c, ldx, _p(out), ho, wo, ldy, _stream())
+    return out
+
+
+def bilinear_bwd(dy, hi, wi):
+    n, ho, wo, c, lddy = geom(dy)
+    dx = new_act(n, hi, wi, c, dy.device)
+    call("iswm_bilinear_bwd", _p(dy), n, hi, wi, c, lddy, ho, wo, _p(dx), c, _stream())
+    return dx
+
+
+def bilinear_to_nchw_fwd(x, c, ho, wo):
+    """NHWC low-res logits (first c channels) -> NCHW [N,c,ho,wo]."""
+    n, hi, wi, cp, ldx = geom(x)
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    call("iswm_bilinear_nhwc_to_nchw_fwd", _p(x), n, hi, wi, c, ldx, _p(y), ho, wo, _stream())
+    return y
+
+
+def bilinear_to_nchw_bwd(dy, hi, wi, cp):
+    n, c, ho, wo = dy.shape
+    assert dy.is_contiguous() and dy.dtype == torch.float32
+    dx = new_act(n, hi, wi, cp, dy.device)
+    call("iswm_bilinear_nhwc_to_nchw_bwd", _p(dy), n, hi, wi, c, cp, ho, wo, _p(dx), _stream())
+    return dx
+
+
+def nchw_to_nhwc(x, cp=None):
+    assert x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    cp = cp or (c + 3) // 4 * 4
+    y = new_act(n, h, w, cp, x.device)
+    call("iswm_nchw_to_nhwc", _p(x), n, c, h * w, _p(y), cp, _stream())
+    return y
+
+
+def nhwc_to_nchw(x, c=None):
+    n, h, w, cc, ld = geom(x)
+    c = c or cc
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    call("iswm_nhwc_to_nchw", _p(x), n, c, h * w, ld, _p(y), _stream())
+    return y
+
+
+def copy_channels(src, dst):
+    m, c, lds = rows(src)
+    md, cd, ldd = rows(dst)
+    assert (m, c) == (md, cd)
+    call("iswm_copy_channels", _p(src), lds, _p(dst), ldd, m, c, _stream())
+    return dst
+
+
+def add_inplace(dst, src):
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    call("iswm_add_inplace", _p(dst), _p(src), dst.numel(), _stream())
+    return dst
+
+
+def dropout_fwd(x, p, seed, offset):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    call("iswm_dropout_fwd", _p(x), _p(y), _p(mask), x.numel(), float(p), int(seed), int(offset), _stream())
+    return y, mask
+
+
+def dropout_bwd(dy, mask, p):
+    assert dy.is_contiguous()
+    dx = torch.empty_like(dy)
+    call("iswm_dropout_bwd", _p(dy), _p(mask), _p(dx), dy.numel(), float(p), _stream())
+    return dx
+
+
+MODE_WCE, MODE_FOCAL_MEAN, MODE_FOCAL_SUM = 0, 1, 2
+
+
+def loss_fwd(logits, labels, weight, ignore_index, alpha, gamma, mode):
+    """Returns (loss[1], sums[2], grad_unnorm) -- one pass over the logits."""
+    assert logits.dim() == 4 and logits.dtype == torch.float32 and logits.is_cuda
+    logits = logits.contiguous()
+    b, c, h, w = logits.shape
+    assert labels.shape == (b, h, w) and labels.dtype in (torch.uint8, torch.int64)
+    labels = labels.contiguous()
+    npix = b * h * w
+    blocks = _lib.load().iswm_loss_blocks(npix)
+    grad = torch.empty_like(logits)
+    partials = torch.empty((2, blocks), dtype=torch.float32, device=logits.device)
+    out = torch.empty((3,), dtype=torch.float32, device=logits.device)  # sums[2], loss
+    call("iswm_loss_fwd", _p(logits), _p(labels), labels.element_size(), b, c, h * w, _p(weight), int(ignore_index),
+         float(alpha), float(gamma), int(mode), _p(grad), _p(partials), _stream())
+    call("iswm_loss_finalize", _p(partials), blocks, int(mode), npix, _p(out), _p(out[2:]), _stream())
+    return out[2:], out[:2], grad
+
+
+def loss_bwd_scale(grad, sums, upstream, mode, npix):
+    call("iswm_loss_bwd_scale", _p(grad), grad.numel(), _p(sums), _p(upstream), int(mode), npix, _stream())
+    return grad
+
+
+def argmax_nchw(logits):
+    logits = logits.contiguous()
+    b, c, h, w = logits.shape
+    out = torch.empty((b, h, w), dtype=torch.int64, device=logits.device)
+    call("iswm_argmax_nchw", _p(logits), b, c, h * w, _p(out), _stream())
+    return out
+
+
+def sgd_step(p, g, buf, lr_dev, momentum, weight_decay, nesterov):
+    call("iswm_sgd_step", _p(p), _p(g), _p(buf), p.numel(), _p(lr_dev), float(momentum), float(weight_decay),
+         int(bool(nesterov)), _stream())
+
+
+def adam_step(p, g, m, v, hyper_dev, beta1, beta2, eps, weight_decay, decoupled):
+    call("iswm_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper_dev), float(beta1), float(beta2),
+         float(eps), float(weight_decay), int(bool(decoupled)), _stream())

@@ -1,0 +1,145 @@
+"""CPU-side checks (no GPU): the C-ABI library builds, loads and exports every symbol the
+header declares; the drop-in construction API yields the reference's state_dict layout; the
+product refuses CPU tensors (no fallback); data-parallel bucketing all-reduces correctly
+over gloo with world_size 2."""
+import os
+import re
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from iswm_amd import _lib
+    from iswm_amd.build import build
+    build(verbose=False)
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "iswm_hip.h")).read()
+    declared = set(re.findall(r"\b(iswm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.iswm_version() >= 100
+
+
+def test_stat_tile_queries_are_pure_host_functions():
+    from iswm_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    d = _lib.ConvDesc(16, 33, 33, 2048, 33, 33, 256, 3, 3, 1, 6, 6, 2048, 256)
+    assert lib.iswm_conv2d_stat_tiles(ctypes.byref(d)) == (16 * 33 * 33 + 127) // 128
+    assert lib.iswm_conv2d_wgrad_workspace(ctypes.byref(d)) % (256 * 9 * 2048 * 4) == 0
+    assert lib.iswm_colstat_tiles(1) == 1 and lib.iswm_colstat_tiles(10 ** 7) == 1024
+    assert lib.iswm_loss_blocks(513 * 513 * 16) == 1024
+
+
+@pytest.mark.parametrize("ctor,backbone,nkeys", [("deeplabv3plus_resnet50", "resnet50", 374),
+                                                 ("deeplabv3plus_resnet101", "resnet101", 680)])
+def test_construction_api_matches_reference_layout(ctor, backbone, nkeys):
+    from iswm_amd.network import modeling
+    from oracle.synth import ArchCfg, param_shapes
+    m = getattr(modeling, ctor)(num_classes=2, output_stride=16)
+    sd = m.state_dict()
+    want = param_shapes(ArchCfg("deeplabv3plus", backbone, 2, 16))
+    assert len(sd) == nkeys
+    assert list(sd.keys()) == list(want.keys())
+    for k, s in want.items():
+        assert tuple(sd[k].shape) == tuple(s), k
+    w = m.backbone.layer4[2].conv2.weight
+    assert w.permute(0, 2, 3, 1).is_contiguous()          # OHWI in memory: what the kernels read
+    assert m.backbone.layer4[1].conv2.dilation == (2, 2) and m.backbone.layer4[0].conv2.dilation == (1, 1)
+    m8 = modeling._segm_resnet("deeplabv3plus", "resnet50", 2, 8, False)
+    assert m8.backbone.layer3[1].conv2.dilation == (2, 2) and m8.backbone.layer4[1].conv2.dilation == (4, 4)
+    assert [c[1][0].dilation[0] for c in list(enumerate(m8.classifier.aspp.convs))[1:4]] == [12, 24, 36]
+
+
+def test_error_conventions():
+    from iswm_amd.network import modeling, utils
+    from iswm_amd.network.backbone import resnet
+    with pytest.raises(NotImplementedError):
+        modeling._load_model("deeplabv3plus", "xception", 2, 16, False)
+    with pytest.raises(ValueError):
+        utils.IntermediateLayerGetter(resnet.resnet50(), {"nope": "out"})
+    with pytest.raises(ValueError):
+        resnet.resnet50(replace_stride_with_dilation=[False, True])
+    names = sorted(n for n in modeling.__dict__ if n.islower() and not n.startswith("_")
+                   and callable(modeling.__dict__[n]))
+    assert "deeplabv3plus_resnet50" in names and "deeplabv3plus_resnet101" in names   # train.py:284-289 scan
+
+
+def test_no_cpu_fallback():
+    from iswm_amd.network import modeling
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    m = modeling.deeplabv3plus_resnet50(num_classes=2, output_stride=16)
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 33, 33))
+    with pytest.raises(ValueError):
+        CrossEntropyLoss()(torch.zeros(1, 2, 4, 4), torch.zeros(1, 4, 4, dtype=torch.int64))
+
+
+def test_oracle_is_not_imported_by_the_product():
+    pkg = os.path.join(ROOT, "iswm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iswm_amd.parallel import DistributedDataParallelHIP
+    torch.manual_seed(rank)                       # different init per rank: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(300, 70), torch.nn.Linear(70, 5000), torch.nn.Linear(5000, 3))
+    ddp = DistributedDataParallelHIP(net, bucket_mb=0.5)
+    params = list(net.parameters())
+    w0 = params[0].detach().clone()
+    assert len(ddp.buckets) >= 2
+    # buckets tile the arena back to front with no gaps
+    assert ddp.buckets[0][1] == ddp.arena.numel and ddp.buckets[-1][0] == 0
+    for (s0, e0), (s1, e1) in zip(ddp.buckets, ddp.buckets[1:]):
+        assert e1 == s0
+    ddp._left = list(ddp._need)
+    for i in range(len(params) - 1, -1, -1):          # backward order
+        p = params[i]
+        p.grad = p._iswm_grad_view
+        p.grad.fill_(float(rank + 1) * (i + 1))
+        ddp._on_ready(p)
+    ddp.finish_grad_sync()
+    ok = all(bool((p.grad == 3.0 * (i + 1)).all()) for i, p in enumerate(params))   # 1 + 2 summed
+    q.put((rank, ok, w0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_bucketed_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert torch.equal(res[0][2], res[1][2])          # rank-0 parameters were broadcast
