@@ -52,7 +52,7 @@ typedef struct {
 /* number of 128-row M tiles of the forward kernel == rows of the BN partials */
 int iswm_conv2d_stat_tiles(const iswm_conv_desc* d);
 /* y = conv(x, w) (+ bias).  If stat_partials != NULL it receives per-M-tile
- * per-channel sums: [2][tiles][Cout] = {sum y, sum y*y} for the training-mode
+ * per-channel statistics [2][tiles][Cout] = {S_t, M2_t} (see iswm_colstat) for the training-mode
  * BatchNorm that follows every conv (network/backbone/resnet.py:89-93). */
 int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const float* w, const float* bias,
                     float* y, float* stat_partials, iswm_stream_t stream);
@@ -68,39 +68,45 @@ int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const float* dy, 
 /* ---- BatchNorm2d (training and eval), ReLU, residual add ---------------------
  * nn.BatchNorm2d eps 1e-5 momentum 0.1 + nn.ReLU + FloatFunctional.add:
  * network/backbone/resnet.py:99-120, network/_deeplab.py:38-39,125-126,135-136. */
-/* per-channel partial sums of a [M, C] (pitch ld) tensor: out[2][tiles][C]; returns
- * tiles through iswm_colstat_tiles(M). */
+/* Tile statistics.  partials[2][tiles][C]: [0] = per-tile column sum S_t, [1] = per-tile
+ * sum of squared deviations from the TILE mean (M2_t).  Tile t covers rows
+ * [t*tile_rows, min(M, (t+1)*tile_rows)).  The conv forward epilogue emits the same pair
+ * with tile_rows = 128 (iswm_conv2d_stat_tiles); iswm_colstat computes it for any [M, C]
+ * (pitch ld) tensor with tiles = ceil(M / iswm_colstat_tile_rows(M)) <= iswm_colstat_tiles(M). */
 int iswm_colstat_tiles(int64_t M);
+int64_t iswm_colstat_tile_rows(int64_t M);
 int iswm_colstat(const float* x, int64_t M, int C, int ld, float* partials, iswm_stream_t stream);
-/* reduce partials -> batch mean / biased var, update running stats (unbiased var,
- * momentum), emit scale = gamma*invstd, shift = beta - mean*scale, and save
- * mean / invstd for backward. */
-int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t count, const float* gamma,
-                     const float* beta, float* running_mean, float* running_var, float momentum,
+/* merge tiles (pairwise/Chan update in double) -> batch mean / biased var, update running
+ * stats (unbiased var, momentum), emit scale = gamma*invstd, shift = beta, and save mean /
+ * invstd (iswm_bn_apply evaluates (y - mean)*scale + shift). */
+int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t count, int64_t tile_rows,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                      iswm_stream_t stream);
 /* eval mode: scale/shift from the running statistics */
 int iswm_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,
                         float* save_mean, float* save_invstd, iswm_stream_t stream);
-/* out = act(y*scale[c] + shift[c] (+ residual)); act = relu if relu != 0 */
+/* out = act((y - mean[c])*scale[c] + shift[c] (+ residual)); act = relu if relu != 0 */
 int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift,
-                  const float* residual, int ldr, int relu, float* out, int ldo,
+                  const float* mean, const float* residual, int ldr, int relu, float* out, int ldo,
                   iswm_stream_t stream);
-/* backward, stage 1: dz = dout * (out > 0 if relu); partial sums of dz and dz*xhat:
- * partials[2][tiles][C] with tiles = iswm_colstat_tiles(M) */
-int iswm_bn_bwd_reduce(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
-                       int64_t M, int C, const float* mean, const float* invstd, int relu,
-                       float* partials, iswm_stream_t stream);
-/* stage 2: finalize dgamma/dbeta from the partials, then
- * dy = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzxhat/M) (training) or gamma*invstd*dz (eval);
- * dres (optional) = dz for the identity branch. */
-int iswm_bn_bwd_finalize(const float* partials, int tiles, int C, float* dgamma, float* dbeta,
+/* backward of out = act(BN(y) (+ residual)):  dz = dout * (out > 0 if relu);
+ *   dbeta = sum dz, dgamma = sum dz*xhat (two deterministic stages, accumulated in double as
+ *   ATen's CPU kernel does);
+ *   dy = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M) (training) or gamma*invstd*dz (eval);
+ *   dres (optional) = dz, the gradient of the identity branch.
+ * workspace: iswm_bn_bwd_workspace(M, C) bytes, 16-byte aligned. */
+size_t iswm_bn_bwd_workspace(int64_t M, int C);
+int iswm_bn_backward(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
+                     int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                     int relu, int training, float* dgamma, float* dbeta, float* dy, int lddy,
+                     float* dres, int lddres, void* workspace, size_t workspace_bytes,
+                     iswm_stream_t stream);
+/* out[c] = sum over tiles of partials[0][t][c] (bias gradient from iswm_colstat partials);
+ * scratch: C floats */
+int iswm_colsum_finalize(const float* partials, int tiles, int C, float* out, float* scratch,
                          iswm_stream_t stream);
-int iswm_bn_bwd_apply(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
-                      int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
-                      const float* dgamma, const float* dbeta, int relu, int training, float* dy,
-                      int lddy, float* dres, int lddres, iswm_stream_t stream);
 
 /* ---- pooling ------------------------------------------------------------------ */
 /* nn.MaxPool2d(3, 2, 1), network/backbone/resnet.py:148.  idx[n,ho,wo,c] = winning

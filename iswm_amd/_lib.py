@@ -29,14 +29,15 @@ _SIGS = {
     "iswm_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "iswm_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
     "iswm_colstat_tiles": (c_int, [c_int64]),
+    "iswm_colstat_tile_rows": (c_int64, [c_int64]),
     "iswm_colstat": (c_int, [P, c_int64, c_int, c_int, P, P]),
-    "iswm_bn_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P]),
+    "iswm_bn_finalize": (c_int, [P, c_int, c_int, c_int64, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P]),
     "iswm_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P, P, P, P]),
-    "iswm_bn_apply": (c_int, [P, c_int64, c_int, c_int, P, P, P, c_int, c_int, P, c_int, P]),
-    "iswm_bn_bwd_reduce": (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P, c_int, P, P]),
-    "iswm_bn_bwd_finalize": (c_int, [P, c_int, c_int, P, P, P]),
-    "iswm_bn_bwd_apply": (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P, P, P, P, c_int, c_int, P,
-                                  c_int, P, c_int, P]),
+    "iswm_bn_apply": (c_int, [P, c_int64, c_int, c_int, P, P, P, P, c_int, c_int, P, c_int, P]),
+    "iswm_bn_bwd_workspace": (c_size_t, [c_int64, c_int]),
+    "iswm_bn_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P, P, c_int, c_int, P, P, P, c_int,
+                                 P, c_int, P, c_size_t, P]),
+    "iswm_colsum_finalize": (c_int, [P, c_int, c_int, P, P, P]),
     "iswm_maxpool3x3s2_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),
     "iswm_maxpool3x3s2_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "iswm_gap_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),

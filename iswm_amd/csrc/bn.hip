@@ -10,69 +10,102 @@
 
 namespace iswm {
 
-// ---- per-channel sum / sum of squares over rows --------------------------------------------
+// ---- per-channel tile statistics: sum and centred sum of squares over a row range ---------
+// tile t covers rows [t*R, min(M, (t+1)*R)); two passes over the tile (the second re-reads it
+// through L2) so that M2 is taken about the tile mean -- see iswm_bn_finalize.
 __global__ __launch_bounds__(256) void k_colstat(const float* __restrict__ x, int64_t M, int C4, int ld,
-                                                 int CQ, int RL, int tiles, int C,
+                                                 int CQ, int RL, int tiles, int C, int64_t R,
                                                  float* __restrict__ partials) {
-    __shared__ float red[2 * 256 * 4];
+    __shared__ float red[256 * 4];
+    __shared__ float mean_s[256 * 4];
     RowThread rt = row_thread(C4, CQ, RL);
-    float4 s = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-    if (rt.active) {
-        const float* p = x + rt.c4 * 4;
-        for (int64_t r = rt.row0; r < M; r += rt.rstep) {
+    const int t = threadIdx.x;
+    const int64_t r_begin = (int64_t)blockIdx.x * R;
+    const int64_t r_end = min(M, r_begin + R);
+    const float cnt = (float)(r_end - r_begin);
+    const float* p = x + rt.c4 * 4;
+    float4 s = make_float4(0, 0, 0, 0);
+    if (rt.active)
+        for (int64_t r = r_begin + rt.rl; r < r_end; r += RL) {
             float4 v = ld4(p + r * ld);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
         }
-    }
-    const int t = threadIdx.x;
     st4(&red[t * 4], s);
-    st4(&red[(256 + t) * 4], s2);
     __syncthreads();
     if (rt.active && rt.rl == 0) {
         for (int k = 1; k < RL; ++k) {
-            float4 a = ld4(&red[(t + k * CQ) * 4]), b = ld4(&red[(256 + t + k * CQ) * 4]);
+            float4 a = ld4(&red[(t + k * CQ) * 4]);
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-            s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
         }
         st4(&partials[(size_t)blockIdx.x * C + rt.c4 * 4], s);
-        st4(&partials[(size_t)(tiles + blockIdx.x) * C + rt.c4 * 4], s2);
+        st4(&mean_s[t * 4], make_float4(s.x / cnt, s.y / cnt, s.z / cnt, s.w / cnt));
+    }
+    __syncthreads();
+    float4 q = make_float4(0, 0, 0, 0);
+    if (rt.active) {
+        const float4 mu = ld4(&mean_s[(t - rt.rl * CQ) * 4]);
+        for (int64_t r = r_begin + rt.rl; r < r_end; r += RL) {
+            float4 v = ld4(p + r * ld);
+            float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+            q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+        }
+    }
+    st4(&red[t * 4], q);
+    __syncthreads();
+    if (rt.active && rt.rl == 0) {
+        for (int k = 1; k < RL; ++k) {
+            float4 a = ld4(&red[(t + k * CQ) * 4]);
+            q.x += a.x; q.y += a.y; q.z += a.z; q.w += a.w;
+        }
+        st4(&partials[(size_t)(tiles + blockIdx.x) * C + rt.c4 * 4], q);
     }
 }
 
-// ---- reduce tiles -> mean/var, running stats, scale/shift ------------------------------------
+// ---- merge tiles -> mean/var, running stats, scale/shift ------------------------------------
+// partials[0][t][c] = S_t (sum over the tile's rows), partials[1][t][c] = M2_t (sum of squared
+// deviations from the tile mean); tile t holds n_t = min(R, count - t*R) rows.
+// mean = sum S_t / N;  M2 = sum [M2_t + n_t (S_t/n_t - mean)^2]   (Chan et al. pairwise update)
 // block = 16 channels x 16 tile lanes
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partials, int tiles, int C,
-                                                     double count, const float* __restrict__ gamma,
+                                                     double count, double R, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* running_mean,
                                                      float* running_var, float momentum, float eps,
                                                      float* scale, float* shift, float* save_mean,
                                                      float* save_invstd) {
-    __shared__ double red[2][16][17];
+    __shared__ double red[16][17];
+    __shared__ double mean_s[16];
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    double s = 0.0, s2 = 0.0;
+    double s = 0.0;
+    if (c < C)
+        for (int k = tl; k < tiles; k += 16) s += (double)partials[(size_t)k * C + c];
+    red[tl][cl] = s;
+    __syncthreads();
+    if (tl == 0) {
+        for (int k = 1; k < 16; ++k) s += red[k][cl];
+        mean_s[cl] = s / count;
+    }
+    __syncthreads();
+    const double mean = mean_s[cl];
+    double m2 = 0.0;
     if (c < C)
         for (int k = tl; k < tiles; k += 16) {
-            s += (double)partials[(size_t)k * C + c];
-            s2 += (double)partials[(size_t)(tiles + k) * C + c];
+            double nt = fmin(R, count - (double)k * R);
+            double d = (double)partials[(size_t)k * C + c] / nt - mean;
+            m2 += (double)partials[(size_t)(tiles + k) * C + c] + nt * d * d;
         }
-    red[0][tl][cl] = s;
-    red[1][tl][cl] = s2;
+    __syncthreads();
+    red[tl][cl] = m2;
     __syncthreads();
     if (tl == 0 && c < C) {
-        for (int k = 1; k < 16; ++k) {
-            s += red[0][k][cl];
-            s2 += red[1][k][cl];
-        }
-        double mean = s / count;
-        double var = s2 / count - mean * mean;
+        for (int k = 1; k < 16; ++k) m2 += red[k][cl];
+        double var = m2 / count;
         if (var < 0.0) var = 0.0;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
         float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         float sc = g * invstd;
         scale[c] = sc;
-        shift[c] = b - (float)mean * sc;
+        shift[c] = b;   // bn_apply evaluates (y - mean)*scale + beta: no cancellation when |mean| >> std
         save_mean[c] = (float)mean;
         save_invstd[c] = invstd;
         if (running_mean) {
@@ -92,7 +125,7 @@ __global__ void k_bn_eval_coeffs(int C, const float* gamma, const float* beta, c
     float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     float sc = g * invstd;
     scale[c] = sc;
-    shift[c] = b - rm[c] * sc;
+    shift[c] = b;
     save_mean[c] = rm[c];
     save_invstd[c] = invstd;
 }
@@ -102,16 +135,18 @@ template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, int64_t M, int C4, int ldy,
                                                   const float* __restrict__ scale,
                                                   const float* __restrict__ shift,
+                                                  const float* __restrict__ mean,
                                                   const float* __restrict__ res, int ldr,
                                                   float* __restrict__ out, int ldo, int CQ, int RL) {
     RowThread rt = row_thread(C4, CQ, RL);
     if (!rt.active) return;
     const int c = rt.c4 * 4;
-    const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+    const float4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c);
     for (int64_t r = rt.row0; r < M; r += rt.rstep) {
         float4 v = ld4(y + r * ldy + c);
         float4 o;
-        o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
+        o.x = (v.x - mu.x) * sc.x + sh.x; o.y = (v.y - mu.y) * sc.y + sh.y;
+        o.z = (v.z - mu.z) * sc.z + sh.z; o.w = (v.w - mu.w) * sc.w + sh.w;
         if (RES) {
             float4 q = ld4(res + r * ldr + c);
             o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
@@ -124,19 +159,24 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
 }
 
 // ---- backward stage 1: partial sums of dz and dz*xhat ----------------------------------------
+// Sums and xhat are formed in double: ATen's CPU BatchNorm backward accumulates in double
+// (acc_type<float, false>), and over a handful of samples (the ASPP image-pooling branch
+// normalises over N x 1 x 1) dy = dz - mean(dz) - xhat*mean(dz*xhat) cancels to ~eps/(var+eps) of
+// its terms, so fp32 rounding of xhat would show up at the 1e-3 level.  The kernels stay HBM-bound.
 template <bool RELU>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dout, int ldd,
                                                        const float* __restrict__ out, int ldo,
                                                        const float* __restrict__ y, int ldy, int64_t M,
                                                        int C4, int C, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, int CQ, int RL,
-                                                       int tiles, float* __restrict__ partials) {
-    __shared__ float red[2 * 256 * 4];
+                                                       int tiles, double* __restrict__ partials) {
+    __shared__ double red[2 * 256 * 4];
     RowThread rt = row_thread(C4, CQ, RL);
-    float4 s = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    double s[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (rt.active) {
         const int c = rt.c4 * 4;
         const float4 mu = ld4(mean + c), is = ld4(invstd + c);
+        const double mud[4] = {mu.x, mu.y, mu.z, mu.w}, isd[4] = {is.x, is.y, is.z, is.w};
         for (int64_t r = rt.row0; r < M; r += rt.rstep) {
             float4 g = ld4(dout + r * ldd + c);
             if (RELU) {
@@ -145,29 +185,40 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
                 g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
             }
             float4 v = ld4(y + r * ldy + c);
-            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-            s2.x += g.x * ((v.x - mu.x) * is.x); s2.y += g.y * ((v.y - mu.y) * is.y);
-            s2.z += g.z * ((v.z - mu.z) * is.z); s2.w += g.w * ((v.w - mu.w) * is.w);
+            const double gd[4] = {g.x, g.y, g.z, g.w}, vd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] += gd[k];
+                s2[k] += gd[k] * ((vd[k] - mud[k]) * isd[k]);
+            }
         }
     }
     const int t = threadIdx.x;
-    st4(&red[t * 4], s);
-    st4(&red[(256 + t) * 4], s2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[t * 4 + k] = s[k];
+        red[(256 + t) * 4 + k] = s2[k];
+    }
     __syncthreads();
     if (rt.active && rt.rl == 0) {
-        for (int k = 1; k < RL; ++k) {
-            float4 a = ld4(&red[(t + k * CQ) * 4]), b = ld4(&red[(256 + t + k * CQ) * 4]);
-            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-            s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+        for (int j = 1; j < RL; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] += red[(t + j * CQ) * 4 + k];
+                s2[k] += red[(256 + t + j * CQ) * 4 + k];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            partials[(size_t)blockIdx.x * C + rt.c4 * 4 + k] = s[k];
+            partials[(size_t)(tiles + blockIdx.x) * C + rt.c4 * 4 + k] = s2[k];
         }
-        st4(&partials[(size_t)blockIdx.x * C + rt.c4 * 4], s);
-        st4(&partials[(size_t)(tiles + blockIdx.x) * C + rt.c4 * 4], s2);
     }
 }
 
-// dbeta = sum dz, dgamma = sum dz*xhat
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partials, int tiles, int C,
-                                                         float* dgamma, float* dbeta) {
+// dbeta = sum dz, dgamma = sum dz*xhat; sums[2][C] keeps them in double for stage 2
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const T* __restrict__ partials, int tiles, int C,
+                                                         float* dgamma, float* dbeta, double* sums) {
     __shared__ double red[2][16][17];
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -187,6 +238,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
         }
         dbeta[c] = (float)s;
         dgamma[c] = (float)s2;
+        if (sums) {
+            sums[c] = s;
+            sums[C + c] = s2;
+        }
     }
 }
 
@@ -195,25 +250,27 @@ template <bool RELU, bool TRAIN, bool DRES>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dout, int ldd,
                                                       const float* __restrict__ out, int ldo,
                                                       const float* __restrict__ y, int ldy, int64_t M,
-                                                      int C4, const float* __restrict__ mean,
+                                                      int C4, int C, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma,
-                                                      const float* __restrict__ dgamma,
-                                                      const float* __restrict__ dbeta, float inv_count,
+                                                      const double* __restrict__ sums, double inv_count,
                                                       float* __restrict__ dy, int lddy,
                                                       float* __restrict__ dres, int lddres, int CQ, int RL) {
     RowThread rt = row_thread(C4, CQ, RL);
     if (!rt.active) return;
     const int c = rt.c4 * 4;
     const float4 mu = ld4(mean + c), is = ld4(invstd + c);
-    float4 ga = gamma ? ld4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 k1 = make_float4(0, 0, 0, 0), k2 = make_float4(0, 0, 0, 0);
+    const float4 ga = gamma ? ld4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const double mud[4] = {mu.x, mu.y, mu.z, mu.w}, isd[4] = {is.x, is.y, is.z, is.w};
+    const double gi[4] = {(double)ga.x * is.x, (double)ga.y * is.y, (double)ga.z * is.z, (double)ga.w * is.w};
+    double k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
     if (TRAIN) {
-        float4 db = ld4(dbeta + c), dg = ld4(dgamma + c);
-        k1 = make_float4(db.x * inv_count, db.y * inv_count, db.z * inv_count, db.w * inv_count);
-        k2 = make_float4(dg.x * inv_count, dg.y * inv_count, dg.z * inv_count, dg.w * inv_count);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            k1[k] = sums[c + k] * inv_count;
+            k2[k] = sums[C + c + k] * inv_count;
+        }
     }
-    const float4 gi = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
     for (int64_t r = rt.row0; r < M; r += rt.rstep) {
         float4 g = ld4(dout + r * ldd + c);
         if (RELU) {
@@ -222,17 +279,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
         }
         if (DRES) st4(dres + r * lddres + c, g);
-        float4 d;
+        const double gd[4] = {g.x, g.y, g.z, g.w};
+        float d[4];
         if (TRAIN) {
             float4 v = ld4(y + r * ldy + c);
-            d.x = gi.x * (g.x - k1.x - (v.x - mu.x) * is.x * k2.x);
-            d.y = gi.y * (g.y - k1.y - (v.y - mu.y) * is.y * k2.y);
-            d.z = gi.z * (g.z - k1.z - (v.z - mu.z) * is.z * k2.z);
-            d.w = gi.w * (g.w - k1.w - (v.w - mu.w) * is.w * k2.w);
+            const double vd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                d[k] = (float)(gi[k] * (gd[k] - k1[k] - (vd[k] - mud[k]) * isd[k] * k2[k]));
         } else {
-            d = make_float4(gi.x * g.x, gi.y * g.y, gi.z * g.z, gi.w * g.w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = (float)(gi[k] * gd[k]);
         }
-        st4(dy + r * lddy + c, d);
+        st4(dy + r * lddy + c, make_float4(d[0], d[1], d[2], d[3]));
     }
 }
 
@@ -253,24 +312,32 @@ extern "C" int iswm_colstat_tiles(int64_t M) {
     return (int)t;
 }
 
+extern "C" int64_t iswm_colstat_tile_rows(int64_t M) {
+    const int64_t tiles = iswm_colstat_tiles(M);
+    return (M + tiles - 1) / tiles;
+}
+
 extern "C" int iswm_colstat(const float* x, int64_t M, int C, int ld, float* partials, iswm_stream_t stream) {
     if (int e = chk_rows("colstat", M, C, ld)) return e;
     ISWM_REQUIRE(x && partials && aligned16(x) && aligned16(partials), "colstat: bad pointer");
-    const int tiles = iswm_colstat_tiles(M);
+    const int64_t R = iswm_colstat_tile_rows(M);
+    const int tiles = (int)((M + R - 1) / R);
     RowPlan p = plan_rows(M, C, tiles);
     hipLaunchKernelGGL(k_colstat, dim3(p.rowblocks, p.colblocks), dim3(256), 0, (hipStream_t)stream, x, M, p.C4,
-                       ld, p.CQ, p.RL, tiles, C, partials);
+                       ld, p.CQ, p.RL, tiles, C, R, partials);
     return check_launch("colstat");
 }
 
-extern "C" int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t count, const float* gamma,
-                                const float* beta, float* running_mean, float* running_var, float momentum,
+extern "C" int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t count, int64_t tile_rows,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                                 float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                                 iswm_stream_t stream) {
-    ISWM_REQUIRE(partials && scale && shift && save_mean && save_invstd && tiles > 0 && C > 0 && count > 0,
-                 "bn_finalize: bad argument");
+    ISWM_REQUIRE(partials && scale && shift && save_mean && save_invstd && tiles > 0 && C > 0 && count > 0 &&
+                     tile_rows > 0 && (int64_t)tiles == (count + tile_rows - 1) / tile_rows,
+                 "bn_finalize: bad argument (tiles %d, count %lld, tile_rows %lld)", tiles, (long long)count,
+                 (long long)tile_rows);
     hipLaunchKernelGGL(k_bn_finalize, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
-                       (double)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                       (double)count, (double)tile_rows, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
                        save_mean, save_invstd);
     return check_launch("bn_finalize");
 }
@@ -286,16 +353,17 @@ extern "C" int iswm_bn_eval_coeffs(int C, const float* gamma, const float* beta,
 }
 
 extern "C" int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift,
-                             const float* residual, int ldr, int relu, float* out, int ldo,
+                             const float* mean, const float* residual, int ldr, int relu, float* out, int ldo,
                              iswm_stream_t stream) {
     if (int e = chk_rows("bn_apply", M, C, ldy)) return e;
-    ISWM_REQUIRE(y && scale && shift && out && ldo % 4 == 0 && ldo >= C, "bn_apply: bad argument");
+    ISWM_REQUIRE(y && scale && shift && mean && out && ldo % 4 == 0 && ldo >= C, "bn_apply: bad argument");
     ISWM_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= C), "bn_apply: bad residual pitch");
     RowPlan p = plan_rows(M, C);
     dim3 grid(p.rowblocks, p.colblocks), blk(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(R, S) \
-    hipLaunchKernelGGL((k_bn_apply<R, S>), grid, blk, 0, s, y, M, p.C4, ldy, scale, shift, residual, ldr, out, ldo, \
+    hipLaunchKernelGGL((k_bn_apply<R, S>), grid, blk, 0, s, y, M, p.C4, ldy, scale, shift, mean, residual, ldr, out, \
+                       ldo, \
                        p.CQ, p.RL)
     if (relu && residual) LAUNCH(true, true);
     else if (relu) LAUNCH(true, false);
@@ -305,49 +373,48 @@ extern "C" int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const fl
     return check_launch("bn_apply");
 }
 
-extern "C" int iswm_bn_bwd_reduce(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
-                                  int64_t M, int C, const float* mean, const float* invstd, int relu,
-                                  float* partials, iswm_stream_t stream) {
-    if (int e = chk_rows("bn_bwd_reduce", M, C, ldy)) return e;
-    ISWM_REQUIRE(dout && y && mean && invstd && partials && (!relu || out), "bn_bwd_reduce: null pointer");
-    ISWM_REQUIRE(ldd % 4 == 0 && ldd >= C && (!relu || (ldo % 4 == 0 && ldo >= C)), "bn_bwd_reduce: bad pitch");
+extern "C" size_t iswm_bn_bwd_workspace(int64_t M, int C) {
+    // double partials[2][tiles][C] + double sums[2][C]
+    return ((size_t)2 * iswm_colstat_tiles(M) * C + (size_t)2 * C) * sizeof(double);
+}
+
+extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
+                                int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                                int relu, int training, float* dgamma, float* dbeta, float* dy, int lddy,
+                                float* dres, int lddres, void* workspace, size_t workspace_bytes,
+                                iswm_stream_t stream) {
+    if (int e = chk_rows("bn_backward", M, C, ldy)) return e;
+    ISWM_REQUIRE(dout && y && mean && invstd && dgamma && dbeta && dy && workspace && (!relu || out),
+                 "bn_backward: null pointer");
+    ISWM_REQUIRE(ldd % 4 == 0 && ldd >= C && lddy % 4 == 0 && lddy >= C && (!relu || (ldo % 4 == 0 && ldo >= C)) &&
+                     (!dres || (lddres % 4 == 0 && lddres >= C)),
+                 "bn_backward: bad pitch");
+    ISWM_REQUIRE(workspace_bytes >= iswm_bn_bwd_workspace(M, C) && aligned16(workspace),
+                 "bn_backward: workspace too small");
     const int tiles = iswm_colstat_tiles(M);
-    RowPlan p = plan_rows(M, C, tiles);
-    dim3 grid(p.rowblocks, p.colblocks), blk(256);
+    double* partials = (double*)workspace;
+    double* sums = partials + (size_t)2 * tiles * C;
     hipStream_t s = (hipStream_t)stream;
-    if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean,
-                           invstd, p.CQ, p.RL, tiles, partials);
-    else
-        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean,
-                           invstd, p.CQ, p.RL, tiles, partials);
-    return check_launch("bn_bwd_reduce");
-}
-
-extern "C" int iswm_bn_bwd_finalize(const float* partials, int tiles, int C, float* dgamma, float* dbeta,
-                                    iswm_stream_t stream) {
-    ISWM_REQUIRE(partials && dgamma && dbeta && tiles > 0 && C > 0, "bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, tiles,
-                       C, dgamma, dbeta);
-    return check_launch("bn_bwd_finalize");
-}
-
-extern "C" int iswm_bn_bwd_apply(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
-                                 int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
-                                 const float* dgamma, const float* dbeta, int relu, int training, float* dy,
-                                 int lddy, float* dres, int lddres, iswm_stream_t stream) {
-    if (int e = chk_rows("bn_bwd_apply", M, C, ldy)) return e;
-    ISWM_REQUIRE(dout && y && mean && invstd && dy && (!relu || out) && (!training || (dgamma && dbeta)),
-                 "bn_bwd_apply: null pointer");
-    ISWM_REQUIRE(ldd % 4 == 0 && ldd >= C && lddy % 4 == 0 && lddy >= C && (!dres || (lddres % 4 == 0 && lddres >= C)),
-                 "bn_bwd_apply: bad pitch");
+    {
+        RowPlan p = plan_rows(M, C, tiles);
+        dim3 grid(p.rowblocks, p.colblocks), blk(256);
+        if (relu)
+            hipLaunchKernelGGL((k_bn_bwd_reduce<true>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C,
+                               mean, invstd, p.CQ, p.RL, tiles, partials);
+        else
+            hipLaunchKernelGGL((k_bn_bwd_reduce<false>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C,
+                               mean, invstd, p.CQ, p.RL, tiles, partials);
+        if (int e = check_launch("bn_bwd_reduce")) return e;
+    }
+    hipLaunchKernelGGL((k_bn_bwd_finalize<double>), dim3((C + 15) / 16), dim3(256), 0, s, partials, tiles, C, dgamma,
+                       dbeta, sums);
+    if (int e = check_launch("bn_bwd_finalize")) return e;
     RowPlan p = plan_rows(M, C);
     dim3 grid(p.rowblocks, p.colblocks), blk(256);
-    hipStream_t s = (hipStream_t)stream;
-    const float inv = 1.f / (float)M;
+    const double inv = 1.0 / (double)M;
 #define LAUNCH(R, T, D)                                                                                          \
-    hipLaunchKernelGGL((k_bn_bwd_apply<R, T, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, mean, invstd, \
-                       gamma, dgamma, dbeta, inv, dy, lddy, dres, lddres, p.CQ, p.RL)
+    hipLaunchKernelGGL((k_bn_bwd_apply<R, T, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean,    \
+                       invstd, gamma, sums, inv, dy, lddy, dres, lddres, p.CQ, p.RL)
     const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
     switch (key) {
         case 0: LAUNCH(false, false, false); break;
@@ -361,4 +428,13 @@ extern "C" int iswm_bn_bwd_apply(const float* dout, int ldd, const float* out, i
     }
 #undef LAUNCH
     return check_launch("bn_bwd_apply");
+}
+
+/* column sums of per-tile partials (bias gradient of a conv with bias): out[c] = sum_t partials[0][t][c] */
+extern "C" int iswm_colsum_finalize(const float* partials, int tiles, int C, float* out, float* scratch,
+                                    iswm_stream_t stream) {
+    ISWM_REQUIRE(partials && out && scratch && tiles > 0 && C > 0, "colsum_finalize: bad argument");
+    hipLaunchKernelGGL((k_bn_bwd_finalize<float>), dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials,
+                       tiles, C, scratch, out, (double*)nullptr);
+    return check_launch("colsum_finalize");
 }

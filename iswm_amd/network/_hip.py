@@ -19,6 +19,11 @@ import torch.nn as nn
 from .. import ops
 
 
+# Test hook: when set to a dict, cba_fwd records {bn_module: (out > 0)} for every fused ReLU so a
+# parity test can hand the CPU oracle the exact sign pattern this path used (tests/test_hip_modules.py).
+MASK_RECORDER = None
+
+
 def pad4(c):
     return (c + 3) // 4 * 4
 
@@ -194,12 +199,7 @@ class Conv2d(HipModule, nn.Conv2d):
         x, g = self._saved
         self._saved = None
         if self.bias is not None and self.bias.requires_grad:
-            partials, tiles = ops.colstat(dy)
-            c = dy.shape[3]
-            tmp = torch.empty((2, c), dtype=torch.float32, device=dy.device)
-            ops.call("iswm_bn_bwd_finalize", ops._p(partials), tiles, c, ops._p(tmp[1]), ops._p(tmp[0]),
-                     ops._stream())
-            sink.target(self.bias).copy_(tmp[0, :self.out_channels])
+            sink.target(self.bias).copy_(ops.colsum(dy)[:self.out_channels])
             sink.done(self.bias)
         self.write_wgrad(x, dy, g, sink)
         if not need_dx:
@@ -260,12 +260,14 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
             # same contract as torch (network/_deeplab.py:130-141 needs batch >= 2)
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" %
                              (tuple(y.shape),))
-        coef = ops.bn_finalize(partials, tiles, count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+        coef = ops.bn_finalize(partials, tiles, count, ops.CONV_STAT_TILE_ROWS, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                bn.momentum, bn.eps)
         bn.num_batches_tracked.add_(1)
     else:
         coef = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     o = ops.bn_apply(y, coef, relu, residual, out)
+    if MASK_RECORDER is not None and relu:
+        MASK_RECORDER[bn] = (o > 0)
     ctx = None
     if save:
         ctx = dict(x=x, y=y, out=o, coef=coef, g=g, relu=relu, training=training, res=residual is not None)

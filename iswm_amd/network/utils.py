@@ -54,6 +54,8 @@ class _SimpleSegmentationModel(nn.Module):
         sink = _hip.GradSink(self._iswm_on_ready)
         dyl = ops.bilinear_to_nchw_bwd(dlogits, hl, wl, cp)
         dfeats = self.classifier.bwd(dyl, sink)
+        if getattr(self, "_debug_keep_dfeats", False):
+            self._debug_dfeats = {k: v.clone() for k, v in dfeats.items()}
         dxh = self.backbone.bwd(dfeats, sink, need_dx)
         return ops.nhwc_to_nchw(dxh, cin) if need_dx else None
 

@@ -125,17 +125,22 @@ def rows(t):
 
 
 def colstat(x):
+    """per-tile column statistics {S_t, M2_t}; returns (partials, tiles, tile_rows)"""
     m, c, ld = rows(x)
-    tiles = _lib.load().iswm_colstat_tiles(m)
+    tile_rows = _lib.load().iswm_colstat_tile_rows(m)
+    tiles = (m + tile_rows - 1) // tile_rows
     partials = torch.empty((2, tiles, c), dtype=torch.float32, device=x.device)
     call("iswm_colstat", _p(x), m, c, ld, _p(partials), _stream())
-    return partials, tiles
+    return partials, tiles, tile_rows
 
 
-def bn_finalize(partials, tiles, count, gamma, beta, running_mean, running_var, momentum, eps=BN_EPS):
+CONV_STAT_TILE_ROWS = 128
+
+
+def bn_finalize(partials, tiles, count, tile_rows, gamma, beta, running_mean, running_var, momentum, eps=BN_EPS):
     c = partials.shape[2]
-    coef = torch.empty((4, c), dtype=torch.float32, device=partials.device)  # scale, shift, mean, invstd
-    call("iswm_bn_finalize", _p(partials), tiles, c, count, _p(gamma), _p(beta), _p(running_mean),
+    coef = torch.empty((4, c), dtype=torch.float32, device=partials.device)  # scale, beta, mean, invstd
+    call("iswm_bn_finalize", _p(partials), tiles, c, count, tile_rows, _p(gamma), _p(beta), _p(running_mean),
          _p(running_var), float(momentum), float(eps), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _stream())
     return coef
 
@@ -158,7 +163,7 @@ def bn_apply(y, coef, relu, residual=None, out=None):
     if residual is not None:
         mr, cr, ldr = rows(residual)
         assert (mr, cr) == (m, c)
-    call("iswm_bn_apply", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(residual), ldr, int(bool(relu)), _p(out),
+    call("iswm_bn_apply", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(residual), ldr, int(bool(relu)), _p(out),
          ldo, _stream())
     return out
 
@@ -168,18 +173,24 @@ def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_d
     m, c, ldy = rows(y)
     _, _, ldd = rows(dout)
     ldo = rows(out)[2] if out is not None else 0
-    tiles = _lib.load().iswm_colstat_tiles(m)
-    partials = torch.empty((2, tiles, c), dtype=torch.float32, device=y.device)
-    call("iswm_bn_bwd_reduce", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]),
-         int(bool(relu)), _p(partials), _stream())
-    call("iswm_bn_bwd_finalize", _p(partials), tiles, c, _p(dgamma), _p(dbeta), _stream())
+    need = _lib.load().iswm_bn_bwd_workspace(m, c)
+    ws = torch.empty((need // 8,), dtype=torch.float64, device=y.device)
     if dy is None:
         dy = torch.empty(y.shape, dtype=torch.float32, device=y.device)
     dres = torch.empty(y.shape, dtype=torch.float32, device=y.device) if want_dres else None
-    call("iswm_bn_bwd_apply", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
-         _p(dgamma), _p(dbeta), int(bool(relu)), int(bool(training)), _p(dy), rows(dy)[2], _p(dres),
-         rows(dres)[2] if dres is not None else 0, _stream())
+    call("iswm_bn_backward", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
+         int(bool(relu)), int(bool(training)), _p(dgamma), _p(dbeta), _p(dy), rows(dy)[2], _p(dres),
+         rows(dres)[2] if dres is not None else 0, _p(ws), need, _stream())
     return dy, dres
+
+
+def colsum(x):
+    """per-channel sum over all pixels (bias gradient)"""
+    partials, tiles, _ = colstat(x)
+    c = x.shape[3]
+    out = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    call("iswm_colsum_finalize", _p(partials), tiles, c, _p(out[0]), _p(out[1]), _stream())
+    return out[0]
 
 
 def maxpool_fwd(x):

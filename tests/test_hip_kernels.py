@@ -56,6 +56,9 @@ CONV_CASES = [
     (256, 4, 1, 1, 0, 1, 33, 33, 2),        # classifier padded to 4 classes
     (2048, 256, 1, 1, 0, 1, 1, 1, 4),       # image-pooling branch: 1x1 spatial
     (128, 512, 1, 1, 0, 1, 40, 40, 3),
+    (1280, 256, 1, 1, 0, 1, 17, 17, 2),     # ASPP projection: dgrad has 10 N-tiles x 5 M-tiles
+    (1280, 256, 1, 1, 0, 1, 25, 25, 2),
+    (512, 64, 1, 1, 0, 1, 17, 17, 2),
 ]
 
 
@@ -75,11 +78,12 @@ def test_conv_fwd_dgrad_wgrad(case):
     g = ops.ConvGeom(xh, cout, k, k, s, p, d)
     y, partials, tiles = ops.conv2d_fwd(xh, w_ohwi, g, want_stats=True)
     assert rel_err(nchw(y), y_ref) < 2e-5
-    # fused BN statistics: per-tile partial sums add up to the column sums
-    ps = partials.double().sum(1).cpu()
+    # fused BN statistics: per-tile {sum, centred M2} merge to the batch mean / variance
+    coef = ops.bn_finalize(partials, tiles, n * g.ho * g.wo, ops.CONV_STAT_TILE_ROWS, None, None, None, None, 0.1)
     yr = y_ref.detach().double()
-    assert rel_err(ps[0], yr.sum((0, 2, 3))) < 1e-4
-    assert rel_err(ps[1], (yr * yr).sum((0, 2, 3))) < 1e-4
+    assert rel_err(coef[2], yr.mean((0, 2, 3))) < 1e-5
+    if n * g.ho * g.wo > 1:
+        assert rel_err(1.0 / coef[3].double().cpu() ** 2 - 1e-5, yr.var((0, 2, 3), unbiased=False)) < 1e-5
     dyh = nhwc(dy)
     dx = ops.conv2d_dgrad(dyh, w_ohwi, g, tuple(xh.shape))
     assert rel_err(nchw(dx), xr.grad) < 2e-5
@@ -129,10 +133,10 @@ def test_batchnorm_train_fwd_bwd(c, m_shape, relu, res):
     o_ref.backward(dout)
 
     yh = nhwc(y)
-    partials, tiles = ops.colstat(yh)
+    partials, tiles, tile_rows = ops.colstat(yh)
     d = dev()
     gd, bd, rmd, rvd = gamma.to(d), beta.to(d), rm.to(d), rv.to(d)
-    coef = ops.bn_finalize(partials, tiles, n * h * w, gd, bd, rmd, rvd, 0.1, 1e-5)
+    coef = ops.bn_finalize(partials, tiles, n * h * w, tile_rows, gd, bd, rmd, rvd, 0.1, 1e-5)
     assert rel_err(rmd, rm_ref) < 1e-5 and rel_err(rvd, rv_ref) < 1e-5
     rh = nhwc(resid) if res else None
     o = ops.bn_apply(yh, coef, relu, rh)
@@ -197,15 +201,16 @@ def test_bilinear_golden():
     for hin, hout, c in BILINEAR_CASES:
         tag = "%d_%d" % (hin, hout)
         x = synth_images(2, hin, hin, seed=51, c=c)
-        y = ops.bilinear_fwd(nhwc(x), hout, hout)
+        cp = (c + 3) // 4 * 4                      # NHWC kernels work on channel groups of 4
+        y = ops.bilinear_fwd(nhwc(x, cp), hout, hout)
         step = int(fx[tag + ".out__cstep"])
-        assert rel_err(nchw(y)[:, ::step], fx[tag + ".out"]) < 1e-5, tag
+        assert rel_err(nchw(y, c)[:, ::step], fx[tag + ".out"]) < 1e-5, tag
         dy = upstream((2, c, hout, hout), 9)
-        dx = ops.bilinear_bwd(nhwc(dy), hin, hin)
+        dx = ops.bilinear_bwd(nhwc(dy, cp), hin, hin)
         step = int(fx[tag + ".grad_x__cstep"])
-        assert rel_err(nchw(dx)[:, ::step], fx[tag + ".grad_x"]) < 1e-5, tag
+        assert rel_err(nchw(dx, c)[:, ::step], fx[tag + ".grad_x"]) < 1e-5, tag
         # fused NHWC -> NCHW variant on the first 2 channels (the logits path)
-        y2 = ops.bilinear_to_nchw_fwd(nhwc(x), 2, hout, hout)
+        y2 = ops.bilinear_to_nchw_fwd(nhwc(x, cp), 2, hout, hout)
         assert rel_err(y2, F.interpolate(x[:, :2], size=(hout, hout), mode="bilinear", align_corners=False)) < 1e-5
         dx2 = ops.bilinear_to_nchw_bwd(dy[:, :2].contiguous().to(dev()), hin, hin, 4)
         xr = x[:, :2].clone().requires_grad_(True)
