@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of DeepLabV3+-ResNet101 (output_stride 16) on
+synthetic 513x513 tiles, 16 images per GPU (BASELINE.json configs[2]: global batch 128 on 8
+GPUs = 16 per GPU; weak scaling), fp32, the train.py:1045-1049 step:
+
+    logits = model(images); loss = criterion(logits, labels);
+    optimizer.zero_grad(); loss.backward(); optimizer.step(); scheduler.step()
+
+with SGD(momentum 0.9, nesterov, wd 1e-4, torch's default lr 1e-3), CosineAnnealingLR and the
+class-weighted CE ([1, 3]) -- all on hand-written gfx950 kernels (libiswm_hip.so).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model resnet101|resnet50]
+                    [--batch B] [--size S] [--no-cpu-baseline]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="resnet101", choices=["resnet50", "resnet101"])
+    ap.add_argument("--output-stride", type=int, default=16, choices=[8, 16])
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=513)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // period))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(model_name, output_stride, size):
+    """The reference's CPU training step restated by oracle/ (kind "port"), timed on this host's
+    cores on a bounded sample: batch 2 (the smallest the image-pooling BatchNorm accepts),
+    1 warm-up + 10 timed steps of the same model and tile size (about 10-20 s)."""
+    import torch
+    from oracle import loss as oloss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.optim import OracleSGD
+    from oracle.synth import ArchCfg, synth_images, synth_labels, synth_state_dict
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    print("[bench] cpu_baseline: %d threads" % cores, file=sys.stderr, flush=True)
+    cfg = ArchCfg("deeplabv3plus", model_name, 2, output_stride)
+    o = OracleDeepLab(cfg, synth_state_dict(cfg), dropout_p=0.1).train()
+    opt = OracleSGD(o.parameters())
+    b = 2
+    x = synth_images(b, size, size, seed=0)
+    lab = synth_labels(b, size, size, seed=0)
+    w = torch.tensor([1.0, 3.0])
+
+    def step():
+        loss = oloss.weighted_ce(o(x), lab, w)
+        o.zero_grad()
+        loss.backward()
+        opt.step()
+
+    t0 = time.perf_counter()
+    step()
+    print("[bench] cpu_baseline: warm-up step %.1f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    n = 10
+    for i in range(n):
+        step()
+        print("[bench] cpu_baseline: step %d done at %.1f s" % (i, time.perf_counter() - t0), file=sys.stderr,
+              flush=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(b * n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed steps (1 warm-up) of oracle/ deeplabv3plus_%s os%d at %dx%d, batch %d, "
+                      "fwd + weighted CE + bwd + SGD-nesterov, torch CPU fp32" %
+                      (n, model_name, output_stride, size, size, b)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from iswm_amd import _lib, ops
+    from iswm_amd.network import modeling
+    from iswm_amd.optim import FusedSGD
+    from iswm_amd.parallel import DistributedDataParallelHIP
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    _lib.load()
+
+    torch.manual_seed(1)                                   # --random_seed 1, train.py:322
+    ctor = {"resnet50": modeling.deeplabv3plus_resnet50, "resnet101": modeling.deeplabv3plus_resnet101}[args.model]
+    model = ctor(num_classes=2, output_stride=args.output_stride).to(dev).train()
+    opt = FusedSGD(model.parameters(), momentum=0.9, weight_decay=1e-4, nesterov=True)   # train.py:426-432
+    group = None
+    net = model
+    if world > 1:
+        group = dist.group.WORLD
+        net = DistributedDataParallelHIP(model, process_group=group)
+        net.attach(opt)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=30000, eta_min=0.01 * 0.01)   # train.py:446-452
+    crit = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]), ignore_index=255, group=group).to(dev)
+
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    B, S = args.batch, args.size
+    images = torch.randn(B, 3, S, S, generator=g).to(dev)
+    labels = (torch.rand(B, S, S, generator=g) < 0.10).to(torch.int64).to(dev)
+
+    def step():
+        logits = net(images)
+        loss = crit(logits, labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    kprof = None
+    if not args.no_kernel_timing:
+        kprof = ops.KernelProfile()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.KPROF = kprof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.KPROF = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss.detach())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "training images/sec (513x513) DeepLabV3+-ResNet101",
+            "value": round(B * world * args.steps / dt, 3),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "deeplabv3plus_%s output_stride=%d, %dx%d synthetic tiles, %d images/GPU "
+                            "(BASELINE.json configs[2]: global batch 128 over 8 GPUs), weighted CE [1,3], "
+                            "SGD-nesterov + cosine LR, fp32 MFMA" % (args.model, args.output_stride, S, S, B),
+                "global_batch": B * world,
+                "parallelism": "dp%d" % world,
+            },
+            "final_loss": round(final_loss, 6),
+        }
+        if kprof is not None:
+            summ = kprof.summary()
+            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            name, d = dom
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {
+                "kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches": d["launches"], "avg_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                "flops_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                "by_kernel": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                  "launches_per_step": v["launches"] // args.steps}
+                              for k, v in sorted(summ.items())},
+                "conv_ms_per_step": round(sum(v["ms"] for v in summ.values()) / args.steps, 3),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model, args.output_stride, S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,8 +171,10 @@ class Conv2d(HipModule, nn.Conv2d):
     def geometry(self, x):
         if x.shape[3] != self.cin_p:
             raise ValueError("conv expects %d (padded) input channels, got %d" % (self.cin_p, x.shape[3]))
-        return ops.ConvGeom(x, self.cout_p, self.kernel_size[0], self.kernel_size[1], self.stride[0],
-                            self.padding[0], self.dilation[0])
+        g = ops.ConvGeom(x, self.cout_p, self.kernel_size[0], self.kernel_size[1], self.stride[0],
+                         self.padding[0], self.dilation[0])
+        g.alg_cin, g.alg_cout = self.in_channels, self.out_channels
+        return g
 
     def write_wgrad(self, x, dy, g, sink):
         """weight gradient straight into p.grad's memory when it is OHWI-dense."""

@@ -51,6 +51,60 @@ def new_act(n, h, w, c, device):
     return torch.empty((n, h, w, c), dtype=torch.float32, device=device)
 
 
+class KernelProfile:
+    """Optional per-launch timing of the conv kernels with HIP events recorded on the stream the
+    kernels are launched on (torch's current stream).  bench.py turns it on for the timed region to
+    report the MFMA roofline fraction; it is off (None) otherwise and costs nothing."""
+
+    def __init__(self):
+        self.records = []   # (kernel name, start event, end event, algorithmic flops)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, start, flops, tag=None):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((name, start, e, flops, tag))
+
+    def summary(self):
+        """{name: dict(launches, ms, flops)} -- call after torch.cuda.synchronize()"""
+        out = {}
+        for name, a, b, fl, _ in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += fl
+        return out
+
+    def by_geometry(self):
+        """{(name, geometry tag): dict(launches, ms, flops)}"""
+        out = {}
+        for name, a, b, fl, tag in self.records:
+            d = out.setdefault((name, tag), dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += fl
+        return out
+
+
+KPROF = None
+
+
+def _valid_taps(h, ho, k, stride, pad, dil):
+    """number of (output index, tap) pairs whose input index is in bounds"""
+    n = 0
+    for t in range(k):
+        off = t * dil - pad
+        # count o in [0, ho) with 0 <= o*stride + off < h
+        o_min = 0 if off >= 0 else (-off + stride - 1) // stride
+        o_max = min(ho - 1, (h - 1 - off) // stride) if h - 1 - off >= 0 else -1
+        n += max(0, o_max - o_min + 1)
+    return n
+
+
 def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -64,10 +118,30 @@ class ConvGeom:
         self.kh, self.kw, self.stride, self.pad, self.dil = kh, kw, stride, pad, dil
         self.ho = conv_out_size(h, kh, stride, pad, dil)
         self.wo = conv_out_size(w, kw, stride, pad, dil)
+        self.alg_cin, self.alg_cout = cin, cout      # un-padded channel counts (set by the module)
+        self._flops = None
+
+    def tag(self):
+        return "n%d %dx%d c%d->%d k%d s%d d%d" % (self.n, self.h, self.w, self.alg_cin, self.alg_cout, self.kh,
+                                                  self.stride, self.dil)
+
+    def flops(self):
+        """algorithmic FLOPs = 2 x MACs over IN-BOUNDS taps only; identical for the
+        forward, data-gradient and weight-gradient passes"""
+        if self._flops is None:
+            vh = _valid_taps(self.h, self.ho, self.kh, self.stride, self.pad, self.dil)
+            vw = _valid_taps(self.w, self.wo, self.kw, self.stride, self.pad, self.dil)
+            self._flops = 2.0 * self.n * vh * vw * self.alg_cin * self.alg_cout
+        return self._flops
 
     def desc(self, ldx, ldy):
         return ConvDesc(self.n, self.h, self.w, self.cin, self.ho, self.wo, self.cout, self.kh, self.kw,
                         self.stride, self.pad, self.dil, ldx, ldy)
+
+
+def _tile_n(c):
+    """N-tile width the C++ launcher picks for c output columns (conv_mfma.hip)"""
+    return 64 if (c <= 64 or (c % 128 != 0 and c % 128 <= 64)) else 128
 
 
 def _check_w(w_ohwi, g):
@@ -89,7 +163,10 @@ def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
     if want_stats:
         tiles = _lib.load().iswm_conv2d_stat_tiles(ctypes.byref(d))
         partials = torch.empty((2, tiles, g.cout), dtype=torch.float32, device=x.device)
+    t0 = KPROF.begin() if KPROF is not None else None
     call("iswm_conv2d_fwd", ctypes.byref(d), _p(x), _p(w_ohwi), _p(bias), _p(out), _p(partials), _stream())
+    if t0 is not None:
+        KPROF.end("k_conv_fwd<%d>" % _tile_n(g.cout), t0, g.flops(), g.tag())
     return out, partials, tiles
 
 
@@ -102,7 +179,10 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
         dx = new_act(*x_like_shape, dy.device)
     ldx = geom(dx)[4]
     d = g.desc(ldx, ldy)
+    t0 = KPROF.begin() if KPROF is not None else None
     call("iswm_conv2d_dgrad", ctypes.byref(d), _p(dy), _p(w_ohwi), _p(dx), int(bool(accumulate)), _stream())
+    if t0 is not None:
+        KPROF.end("k_conv_dgrad<%d>" % _tile_n(g.cin), t0, g.flops(), g.tag())
     return dx
 
 
@@ -115,7 +195,12 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
     d = g.desc(ldx, ldy)
     need = _lib.load().iswm_conv2d_wgrad_workspace(ctypes.byref(d))
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device) if need else None
+    t0 = KPROF.begin() if KPROF is not None else None
     call("iswm_conv2d_wgrad", ctypes.byref(d), _p(x), _p(dy), _p(dw_ohwi), _p(ws), need, _stream())
+    if t0 is not None:
+        ktot = g.kh * g.kw * g.cin
+        big = g.cout % 128 == 0 and (ktot % 128 == 0 or ktot >= 1024)
+        KPROF.end("k_conv_wgrad<%s>+reduce" % ("128,128" if big else "64,64"), t0, g.flops(), g.tag())
     return dw_ohwi
 
 
