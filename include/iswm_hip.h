@@ -49,7 +49,12 @@ typedef struct {
     int ldy;            /* pixel pitch of y  (floats) */
 } iswm_conv_desc;
 
-/* number of 128-row M tiles of the forward kernel == rows of the BN partials */
+/* name of the device kernel a call with this geometry launches (kind 0 fwd, 1 dgrad, 2 wgrad) --
+ * lets a profiler label its timings with the symbol rocprofv3 reports */
+int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen);
+/* M tiling the forward kernel will use for this geometry: rows per tile (128 or 64) and number of
+ * tiles == rows of the BN partials */
+int iswm_conv2d_stat_tile_rows(const iswm_conv_desc* d);
 int iswm_conv2d_stat_tiles(const iswm_conv_desc* d);
 /* y = conv(x, w) (+ bias).  If stat_partials != NULL it receives per-M-tile
  * per-channel statistics [2][tiles][Cout] = {S_t, M2_t} (see iswm_colstat) for the training-mode

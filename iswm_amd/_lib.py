@@ -23,6 +23,8 @@ _SIGS = {
     # name: (restype, [argtypes])
     "iswm_last_error": (c_char_p, []),
     "iswm_version": (c_int, []),
+    "iswm_conv2d_kernel_name": (c_int, [POINTER(ConvDesc), c_int, c_char_p, c_int]),
+    "iswm_conv2d_stat_tile_rows": (c_int, [POINTER(ConvDesc)]),
     "iswm_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
     "iswm_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "iswm_conv2d_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),

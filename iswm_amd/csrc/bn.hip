@@ -65,31 +65,33 @@ __global__ __launch_bounds__(256) void k_colstat(const float* __restrict__ x, in
 // partials[0][t][c] = S_t (sum over the tile's rows), partials[1][t][c] = M2_t (sum of squared
 // deviations from the tile mean); tile t holds n_t = min(R, count - t*R) rows.
 // mean = sum S_t / N;  M2 = sum [M2_t + n_t (S_t/n_t - mean)^2]   (Chan et al. pairwise update)
-// block = 16 channels x 16 tile lanes
+// block = CPB channels x (256 / CPB) tile lanes: many tiles (large maps) want more lanes per channel
+template <int CPB>
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partials, int tiles, int C,
                                                      double count, double R, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* running_mean,
                                                      float* running_var, float momentum, float eps,
                                                      float* scale, float* shift, float* save_mean,
                                                      float* save_invstd) {
-    __shared__ double red[16][17];
-    __shared__ double mean_s[16];
-    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    constexpr int TL = 256 / CPB;
+    __shared__ double red[TL][CPB + 1];
+    __shared__ double mean_s[CPB];
+    const int cl = threadIdx.x % CPB, tl = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl;
     double s = 0.0;
     if (c < C)
-        for (int k = tl; k < tiles; k += 16) s += (double)partials[(size_t)k * C + c];
+        for (int k = tl; k < tiles; k += TL) s += (double)partials[(size_t)k * C + c];
     red[tl][cl] = s;
     __syncthreads();
     if (tl == 0) {
-        for (int k = 1; k < 16; ++k) s += red[k][cl];
+        for (int k = 1; k < TL; ++k) s += red[k][cl];
         mean_s[cl] = s / count;
     }
     __syncthreads();
     const double mean = mean_s[cl];
     double m2 = 0.0;
     if (c < C)
-        for (int k = tl; k < tiles; k += 16) {
+        for (int k = tl; k < tiles; k += TL) {
             double nt = fmin(R, count - (double)k * R);
             double d = (double)partials[(size_t)k * C + c] / nt - mean;
             m2 += (double)partials[(size_t)(tiles + k) * C + c] + nt * d * d;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     red[tl][cl] = m2;
     __syncthreads();
     if (tl == 0 && c < C) {
-        for (int k = 1; k < 16; ++k) m2 += red[k][cl];
+        for (int k = 1; k < TL; ++k) m2 += red[k][cl];
         double var = m2 / count;
         if (var < 0.0) var = 0.0;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -336,9 +338,14 @@ extern "C" int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t
                      tile_rows > 0 && (int64_t)tiles == (count + tile_rows - 1) / tile_rows,
                  "bn_finalize: bad argument (tiles %d, count %lld, tile_rows %lld)", tiles, (long long)count,
                  (long long)tile_rows);
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
-                       (double)count, (double)tile_rows, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
-                       save_mean, save_invstd);
+    if (tiles > 128)
+        hipLaunchKernelGGL((k_bn_finalize<4>), dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
+                           (double)count, (double)tile_rows, gamma, beta, running_mean, running_var, momentum, eps,
+                           scale, shift, save_mean, save_invstd);
+    else
+        hipLaunchKernelGGL((k_bn_finalize<16>), dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, tiles,
+                           C, (double)count, (double)tile_rows, gamma, beta, running_mean, running_var, momentum, eps,
+                           scale, shift, save_mean, save_invstd);
     return check_launch("bn_finalize");
 }
 

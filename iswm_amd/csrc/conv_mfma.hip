@@ -24,34 +24,9 @@
 //     the training-mode BatchNorm that follows every conv (deterministic two-stage stats);
 //   * wgrad flattens (tap, cin) into the GEMM N axis and splits the pixel (K) axis across
 //     workgroups into slabs that a second kernel sums in a fixed order (bit-reproducible).
-#include "common.h"
+#include "conv_common.h"
 
 namespace iswm {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    const float* bias;
-    float* y;
-    float* stats;
-    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, ldx, ldy;
-    int M;       // GEMM rows
-    int Ktot;    // GEMM K (fwd/dgrad) or flattened N (wgrad)
-    int MT, NT;  // tile counts
-    int nsplit;  // wgrad: K splits
-    int psplit;  // wgrad: pixels per split (multiple of 32)
-    int accumulate;  // dgrad: dx += result instead of dx = result
-};
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-constexpr int KC_PITCH = 36;  // floats per LDS row of a K-contiguous operand tile (32 + 4 pad)
 
 // ------------------------------------------------------------------------------------------
 // forward:  y[m, co] = sum_k A[m, k] * W[co, k],  m = (n, oh, ow),  k = (kh, kw, ci)
@@ -400,17 +375,61 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
     const int dh = kh * a.dil - a.pad, dw = kw * a.dil - a.pad;
 
-    // pixel coordinates of this thread's B rows, advanced by 32 pixels per chunk
+    // pixel coordinates (n, oh, ow) of this thread's B rows for the CURRENT chunk; advanced by 32 pixels
+    // per chunk with a branch-free carry (falls back to division on tiny maps)
     int bn_[BPASS], boh[BPASS], bow[BPASS];
     const int HoWo = a.Ho * a.Wo;
+    const int d_oh = 32 / a.Wo, d_ow = 32 - d_oh * a.Wo;
+    const bool fast_adv = d_oh + 1 <= a.Ho;
+    auto decode = [&](int kc) {
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) {
-        int p = p_begin + bk0 + BKR * j;
-        int n = p / HoWo, rem = p - n * HoWo;
-        bn_[j] = n;
-        boh[j] = rem / a.Wo;
-        bow[j] = rem - boh[j] * a.Wo;
-    }
+        for (int j = 0; j < BPASS; ++j) {
+            int p = p_begin + kc * 32 + bk0 + BKR * j;
+            int n = p / HoWo, rem = p - n * HoWo;
+            bn_[j] = n;
+            boh[j] = rem / a.Wo;
+            bow[j] = rem - boh[j] * a.Wo;
+        }
+    };
+    auto advance = [&](int kc) {
+        if (!fast_adv) {
+            decode(kc);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            int ow = bow[j] + d_ow;
+            int c1 = ow >= a.Wo ? 1 : 0;
+            bow[j] = ow - (c1 ? a.Wo : 0);
+            int oh = boh[j] + d_oh + c1;
+            int c2 = oh >= a.Ho ? 1 : 0;
+            boh[j] = oh - (c2 ? a.Ho : 0);
+            bn_[j] += c2;
+        }
+    };
+    decode(0);
+
+    // Row culling: when every column of this tile belongs to ONE filter tap (kh fixed), output rows whose
+    // input row oh*stride + kh*dil - pad is outside the image contribute nothing -- whole 32-pixel chunks
+    // inside such rows (the ASPP rates on a 33x33 map) are skipped.
+    const int n4_last = (min(n0 + BN, a.Ktot) >> 2) - 1;
+    const int tap_last = n4_last / Cin4;
+    const int tap_first = (n0 >> 2) / Cin4;
+    const int kh_u = tap_first / a.KW;
+    const int off_u = kh_u * a.dil - a.pad;
+    // valid oh: 0 <= oh*stride + off_u <= H-1
+    const int oh_lo = off_u >= 0 ? 0 : (-off_u + a.stride - 1) / a.stride;
+    const int oh_hi = (a.H - 1 - off_u) >= 0 ? min(a.Ho - 1, (a.H - 1 - off_u) / a.stride) : -1;
+    const bool cull = (tap_first / a.KW == tap_last / a.KW) && (oh_lo > 0 || oh_hi < a.Ho - 1) && HoWo >= 64;
+    auto skip = [&](int kc) -> bool {   // block-uniform
+        if (!cull) return false;
+        const int p0 = p_begin + kc * 32, p1 = min(p0 + 31, p_end - 1);
+        const int n0_ = p0 / HoWo, oh0 = (p0 - n0_ * HoWo) / a.Wo;
+        const int n1_ = p1 / HoWo, oh1 = (p1 - n1_ * HoWo) / a.Wo;
+        if (n0_ == n1_) return oh1 < oh_lo || oh0 > oh_hi;          // rows oh0..oh1 of one image
+        if (n1_ == n0_ + 1) return oh0 > oh_hi && oh1 < oh_lo;      // tail of one image + head of the next
+        return false;
+    };
 
     float4 ra[APASS], rb[BPASS];
     auto gload = [&](int kc) {
@@ -427,16 +446,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
             bool ok = bok && p < p_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
             rb[j] = ok ? ldg4(a.x + (size_t)((bn_[j] * a.H + ih) * a.W + iw) * a.ldx + c4 * 4)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
-            // advance to the next chunk's pixel
-            bow[j] += 32;
-            while (bow[j] >= a.Wo) {
-                bow[j] -= a.Wo;
-                boh[j] += 1;
-            }
-            while (boh[j] >= a.Ho) {
-                boh[j] -= a.Ho;
-                bn_[j] += 1;
-            }
         }
     };
     auto lstore = [&](int buf) {
@@ -457,15 +466,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nK = (p_end - p_begin + 31) >> 5;
-    if (nK > 0) {
-        gload(0);
+    int kc = 0;
+    bool first = true;
+    auto next = [&]() -> bool {   // move to the next chunk that has work (coordinates follow kc)
+        for (;;) {
+            if (!first) {
+                ++kc;
+                if (kc < nK) advance(kc);
+            }
+            first = false;
+            if (kc >= nK) return false;
+            if (!skip(kc)) return true;
+        }
+    };
+    bool more = next();
+    if (more) {
+        gload(kc);
         lstore(0);
     }
     __syncthreads();
-    for (int kc = 0; kc < nK; ++kc) {
-        const int cur = kc & 1;
-        const bool more = kc + 1 < nK;
-        if (more) gload(kc + 1);
+    int cur = 0;
+    while (more) {
+        const bool more2 = next();
+        if (more2) gload(kc);
         const float* Ab = &As[(cur * 32 + lh * 4) * BM + wm * (BM / 2) + li];
         const float* Bb = &Bs[(cur * 32 + lh * 4) * BN + wn * (BN / 2) + li];
 #pragma unroll
@@ -487,8 +510,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
                     for (int nb = 0; nb < NB; ++nb)
                         acc[mb][nb] = mfma32(af[mb][j], bf[nb][j], acc[mb][nb]);
         }
-        if (more) lstore(cur ^ 1);
+        if (more2) lstore(cur ^ 1);
         __syncthreads();
+        cur ^= 1;
+        more = more2;
     }
     float* out = a.stats + (size_t)split * a.Cout * a.Ktot;  // slab (or dw itself when nsplit == 1)
 #pragma unroll
@@ -539,6 +564,18 @@ static int validate(const iswm_conv_desc* d) {
     return 0;
 }
 
+// Tile-width choice for the forward / dgrad kernels.  A CU works through ceil(tiles/256) tiles
+// (co-resident workgroups share its SIMDs), so a 128x128 grid of 274 tiles (the 33x33 stages with 256
+// output channels) costs two full tile times where 128x64 tiles cost three half tile times.
+// Narrow tiles re-read the activation panel once more and pay ~10 % in MFMA:staging ratio.
+static bool use_narrow_tile(int64_t MT, int cols) {
+    if (cols <= 64 || (cols % 128 != 0 && cols % 128 <= 64)) return true;
+    const int64_t t128 = MT * ((cols + 127) / 128), t64 = MT * ((cols + 63) / 64);
+    const double c128 = (double)((t128 + 255) / 256) * 128.0;
+    const double c64 = (double)((t64 + 255) / 256) * 64.0 * 1.10;
+    return c64 < c128;
+}
+
 static ConvArgs base_args(const iswm_conv_desc* d) {
     ConvArgs a{};
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin;
@@ -577,10 +614,41 @@ static WgradPlan plan_wgrad(const iswm_conv_desc* d) {
 
 using namespace iswm;
 
+extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
+    ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 2, "kernel_name: bad argument");
+    int bm, bn;
+    if (kind == 0) {
+        const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+        if (d->Cin % 32 == 0) {
+            conv_pick_tile(M, d->Cout, &bm, &bn);
+            snprintf(buf, buflen, "k_conv_fwd_u<%d, %d>", bm, bn);
+        } else {
+            snprintf(buf, buflen, "k_conv_fwd<%d>", use_narrow_tile((M + 127) / 128, d->Cout) ? 64 : 128);
+        }
+    } else if (kind == 1) {
+        const int64_t M = (int64_t)d->N * d->H * d->W;
+        if (d->Cout % 32 == 0) {
+            conv_pick_tile(M, d->Cin, &bm, &bn);
+            snprintf(buf, buflen, "k_conv_dgrad_u<%d, %d>", bm, bn);
+        } else {
+            snprintf(buf, buflen, "k_conv_dgrad<%d>", use_narrow_tile((M + 127) / 128, d->Cin) ? 64 : 128);
+        }
+    } else {
+        WgradPlan p = plan_wgrad(d);
+        snprintf(buf, buflen, "k_conv_wgrad<%d, %d>", p.bm, p.bn);
+    }
+    return 0;
+}
+
+extern "C" int iswm_conv2d_stat_tile_rows(const iswm_conv_desc* d) {
+    if (!d) return 0;
+    return conv_fwd_tile_rows((int64_t)d->N * d->Ho * d->Wo, d->Cin, d->Cout);
+}
+
 extern "C" int iswm_conv2d_stat_tiles(const iswm_conv_desc* d) {
     if (!d) return 0;
-    int64_t M = (int64_t)d->N * d->Ho * d->Wo;
-    return (int)((M + 127) / 128);
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo, R = iswm_conv2d_stat_tile_rows(d);
+    return (int)((M + R - 1) / R);
 }
 
 extern "C" int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -594,7 +662,8 @@ extern "C" int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const fl
     a.Ktot = d->KH * d->KW * d->Cin;
     a.MT = (a.M + 127) / 128;
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout % 128 <= 64)) {
+    if (launch_conv_fwd_u(a, s)) return check_launch("conv_fwd_u");
+    if (use_narrow_tile(a.MT, d->Cout)) {
         a.NT = (d->Cout + 63) / 64;
         hipLaunchKernelGGL(k_conv_fwd<64>, dim3(a.MT * a.NT), dim3(256), 0, s, a);
     } else {
@@ -617,7 +686,8 @@ extern "C" int iswm_conv2d_dgrad(const iswm_conv_desc* d, const float* dy, const
     a.Ktot = d->KH * d->KW * d->Cout;
     a.MT = (a.M + 127) / 128;
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cin <= 64 || (d->Cin % 128 != 0 && d->Cin % 128 <= 64)) {
+    if (launch_conv_dgrad_u(a, s)) return check_launch("conv_dgrad_u");
+    if (use_narrow_tile(a.MT, d->Cin)) {
         a.NT = (d->Cin + 63) / 64;
         hipLaunchKernelGGL(k_conv_dgrad<64>, dim3(a.MT * a.NT), dim3(256), 0, s, a);
     } else {

@@ -262,9 +262,10 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
             # same contract as torch (network/_deeplab.py:130-141 needs batch >= 2)
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" %
                              (tuple(y.shape),))
-        coef = ops.bn_finalize(partials, tiles, count, ops.CONV_STAT_TILE_ROWS, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+        coef = ops.bn_finalize(partials, tiles[0], count, tiles[1], bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                bn.momentum, bn.eps)
-        bn.num_batches_tracked.add_(1)
+        if not getattr(bn, "_iswm_nbt_fused", False):
+            bn.num_batches_tracked.add_(1)     # models built by modeling.* bump all counters in ONE op
     else:
         coef = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     o = ops.bn_apply(y, coef, relu, residual, out)
@@ -294,6 +295,20 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
     else:
         dx = None
     return dx, dres
+
+
+def fuse_batch_counters(root):
+    """Re-home every BatchNorm's ``num_batches_tracked`` into one int64 tensor so a training forward
+    bumps all of them with a single op (113 tiny launches per step for ResNet-101 otherwise).  The
+    buffers stay registered under their usual state_dict keys (they become views)."""
+    bns = [m for m in root.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+    if not bns:
+        return None
+    flat = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in bns]).contiguous()
+    for i, m in enumerate(bns):
+        m._buffers["num_batches_tracked"] = flat[i]
+        m._iswm_nbt_fused = True
+    return flat
 
 
 class HipSequential(HipModule, nn.Sequential):

@@ -38,8 +38,25 @@ class _SimpleSegmentationModel(nn.Module):
         self._iswm_on_ready = None   # set by iswm_amd.parallel for gradient all-reduce overlap
 
     # x NCHW [B,C,H,W] fp32 on the GPU -> logits NCHW [B,num_classes,H,W]
+    def _counters(self):
+        """one flat tensor behind every BatchNorm's num_batches_tracked (rebuilt if the module was
+        moved / reloaded in a way that broke the views)"""
+        flat = getattr(self, "_iswm_nbt", None)
+        first = next((m for m in self.modules() if isinstance(m, nn.BatchNorm2d)), None)
+        if first is None:
+            return None
+        nbt = first.num_batches_tracked
+        if flat is None or flat.device != nbt.device or nbt.data_ptr() != flat.data_ptr():
+            flat = _hip.fuse_batch_counters(self)
+            object.__setattr__(self, "_iswm_nbt", flat)
+        return flat
+
     def _fwd(self, x, save):
         n, c, h, w = x.shape
+        if self.training:
+            flat = self._counters()
+            if flat is not None:
+                flat.add_(1)
         xh = ops.nchw_to_nhwc(x)                               # pads 3 -> 4 channels
         feats = self.backbone.fwd(xh, save)
         yl = self.classifier.fwd(feats, save)                  # [B, hl, wl, pad4(num_classes)]

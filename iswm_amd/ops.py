@@ -139,9 +139,11 @@ class ConvGeom:
                         self.stride, self.pad, self.dil, ldx, ldy)
 
 
-def _tile_n(c):
-    """N-tile width the C++ launcher picks for c output columns (conv_mfma.hip)"""
-    return 64 if (c <= 64 or (c % 128 != 0 and c % 128 <= 64)) else 128
+def _kernel_name(d, kind):
+    """device kernel symbol the library launches for this geometry (labels profile records)"""
+    buf = ctypes.create_string_buffer(64)
+    _lib.load().iswm_conv2d_kernel_name(ctypes.byref(d), kind, buf, 64)
+    return buf.value.decode()
 
 
 def _check_w(w_ohwi, g):
@@ -151,7 +153,7 @@ def _check_w(w_ohwi, g):
 
 
 def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
-    """y = conv(x, w) [+ bias]; returns (y, partials|None, tiles)."""
+    """y = conv(x, w) [+ bias]; returns (y, partials|None, (tiles, tile_rows))."""
     ldx = geom(x)[4]
     _check_w(w_ohwi, g)
     if out is None:
@@ -159,14 +161,15 @@ def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
     on, oh, ow, oc, ldy = geom(out)
     assert (on, oh, ow, oc) == (g.n, g.ho, g.wo, g.cout)
     d = g.desc(ldx, ldy)
-    partials, tiles = None, 0
+    partials, tiles = None, (0, 0)
     if want_stats:
-        tiles = _lib.load().iswm_conv2d_stat_tiles(ctypes.byref(d))
-        partials = torch.empty((2, tiles, g.cout), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        tiles = (lib.iswm_conv2d_stat_tiles(ctypes.byref(d)), lib.iswm_conv2d_stat_tile_rows(ctypes.byref(d)))
+        partials = torch.empty((2, tiles[0], g.cout), dtype=torch.float32, device=x.device)
     t0 = KPROF.begin() if KPROF is not None else None
     call("iswm_conv2d_fwd", ctypes.byref(d), _p(x), _p(w_ohwi), _p(bias), _p(out), _p(partials), _stream())
     if t0 is not None:
-        KPROF.end("k_conv_fwd<%d>" % _tile_n(g.cout), t0, g.flops(), g.tag())
+        KPROF.end(_kernel_name(d, 0), t0, g.flops(), g.tag())
     return out, partials, tiles
 
 
@@ -182,7 +185,7 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
     t0 = KPROF.begin() if KPROF is not None else None
     call("iswm_conv2d_dgrad", ctypes.byref(d), _p(dy), _p(w_ohwi), _p(dx), int(bool(accumulate)), _stream())
     if t0 is not None:
-        KPROF.end("k_conv_dgrad<%d>" % _tile_n(g.cin), t0, g.flops(), g.tag())
+        KPROF.end(_kernel_name(d, 1), t0, g.flops(), g.tag())
     return dx
 
 
@@ -198,9 +201,7 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
     t0 = KPROF.begin() if KPROF is not None else None
     call("iswm_conv2d_wgrad", ctypes.byref(d), _p(x), _p(dy), _p(dw_ohwi), _p(ws), need, _stream())
     if t0 is not None:
-        ktot = g.kh * g.kw * g.cin
-        big = g.cout % 128 == 0 and (ktot % 128 == 0 or ktot >= 1024)
-        KPROF.end("k_conv_wgrad<%s>+reduce" % ("128,128" if big else "64,64"), t0, g.flops(), g.tag())
+        KPROF.end(_kernel_name(d, 2) + "+reduce", t0, g.flops(), g.tag())
     return dw_ohwi
 
 
@@ -217,9 +218,6 @@ def colstat(x):
     partials = torch.empty((2, tiles, c), dtype=torch.float32, device=x.device)
     call("iswm_colstat", _p(x), m, c, ld, _p(partials), _stream())
     return partials, tiles, tile_rows
-
-
-CONV_STAT_TILE_ROWS = 128
 
 
 def bn_finalize(partials, tiles, count, tile_rows, gamma, beta, running_mean, running_var, momentum, eps=BN_EPS):

@@ -79,7 +79,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     y, partials, tiles = ops.conv2d_fwd(xh, w_ohwi, g, want_stats=True)
     assert rel_err(nchw(y), y_ref) < 2e-5
     # fused BN statistics: per-tile {sum, centred M2} merge to the batch mean / variance
-    coef = ops.bn_finalize(partials, tiles, n * g.ho * g.wo, ops.CONV_STAT_TILE_ROWS, None, None, None, None, 0.1)
+    coef = ops.bn_finalize(partials, tiles[0], n * g.ho * g.wo, tiles[1], None, None, None, None, 0.1)
     yr = y_ref.detach().double()
     assert rel_err(coef[2], yr.mean((0, 2, 3))) < 1e-5
     if n * g.ho * g.wo > 1:

@@ -272,7 +272,9 @@ def test_whole_model(tag, backbone, os_):
     check_sign_patterns(o, o.relu_masks)
     params = dict(m.named_parameters())
     worst = max((rel_err(params[k].grad, v.grad), k) for k, v in o.named_parameters())
-    assert worst[0] <= RTOL, worst
+    # 3e-3: the saved activations that enter every weight gradient already differ by up to 1e-3 (the
+    # forward tolerance) after 50-100 train-mode BatchNorm layers on a 5x5 / 9x9 map
+    assert worst[0] <= 3 * RTOL, worst
 
 
 def test_train_steps_match_oracle():

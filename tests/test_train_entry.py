@@ -1,0 +1,32 @@
+"""The train.py counterpart end to end on the GPU: a few iterations, validation with argmax masks,
+checkpoint in the reference's dictionary format, and resume (train.py:525-609, 972-1016)."""
+import glob
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_validate_checkpoint_resume(tmp_path, capsys):
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from iswm_amd import train
+    ck = str(tmp_path / "ck")
+    base = ["--model", "deeplabv3plus_resnet50", "--crop_size", "65", "--batch_size", "4", "--synthetic_len", "16",
+            "--optimizer", "sgd", "--loss_type", "IWce_loss", "--print_interval", "2", "--val_interval", "2",
+            "--val_batch_size", "4", "--checkpoints_dir", ck]
+    train.main(base + ["--total_itrs", "4"])
+    out = capsys.readouterr().out
+    assert "Itrs 4/4" in out and "Validation @2" in out
+    files = glob.glob(os.path.join(ck, "best_*.pth"))
+    assert len(files) == 1
+    ckpt = torch.load(files[0], map_location="cpu", weights_only=True)
+    for key in ("model_state", "optimizer_state", "scheduler_state", "cur_itrs", "best_score", "model_config"):
+        assert key in ckpt
+    assert len(ckpt["model_state"]) == 374
+    assert ckpt["model_config"]["model_name"] == "deeplabv3plus_resnet50"
+    train.main(base + ["--total_itrs", "6", "--ckpt", files[0], "--continue_training"])
+    out = capsys.readouterr().out
+    assert "Model restored" in out and "Itrs 6/6" in out
