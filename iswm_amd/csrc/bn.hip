@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
 // (acc_type<float, false>), and over a handful of samples (the ASPP image-pooling branch
 // normalises over N x 1 x 1) dy = dz - mean(dz) - xhat*mean(dz*xhat) cancels to ~eps/(var+eps) of
 // its terms, so fp32 rounding of xhat would show up at the 1e-3 level.  The kernels stay HBM-bound.
-template <bool RELU>
+template <bool RELU, bool DBL>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dout, int ldd,
                                                        const float* __restrict__ out, int ldo,
                                                        const float* __restrict__ y, int ldy, int64_t M,
@@ -178,20 +178,40 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
     if (rt.active) {
         const int c = rt.c4 * 4;
         const float4 mu = ld4(mean + c), is = ld4(invstd + c);
-        const double mud[4] = {mu.x, mu.y, mu.z, mu.w}, isd[4] = {is.x, is.y, is.z, is.w};
-        for (int64_t r = rt.row0; r < M; r += rt.rstep) {
-            float4 g = ld4(dout + r * ldd + c);
-            if (RELU) {
-                float4 o = ld4(out + r * ldo + c);
-                g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
-                g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        // fp32 partial sums over runs of 8 rows (4 loads x 3 tensors in flight per step), flushed into
+        // double: keeps the double-accumulated result to ~1e-7 while staying load-bound, not DP-latency-bound
+        for (int64_t r = rt.row0; r < M; r += 8 * rt.rstep) {
+            float f[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t rr = r + u * rt.rstep;
+                if (rr < M) {
+                    float4 g = ld4(dout + rr * ldd + c);
+                    if (RELU) {
+                        float4 o = ld4(out + rr * ldo + c);
+                        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+                        g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+                    }
+                    float4 v = ld4(y + rr * ldy + c);
+                    if (DBL) {   // few rows per channel (image-pooling branch): everything in double
+                        const double gd[4] = {g.x, g.y, g.z, g.w}, vd[4] = {v.x, v.y, v.z, v.w};
+                        const double mud[4] = {mu.x, mu.y, mu.z, mu.w}, isd[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            s[k] += gd[k];
+                            s2[k] += gd[k] * ((vd[k] - mud[k]) * isd[k]);
+                        }
+                    } else {
+                        f[0] += g.x; f[1] += g.y; f[2] += g.z; f[3] += g.w;
+                        f2[0] += g.x * ((v.x - mu.x) * is.x); f2[1] += g.y * ((v.y - mu.y) * is.y);
+                        f2[2] += g.z * ((v.z - mu.z) * is.z); f2[3] += g.w * ((v.w - mu.w) * is.w);
+                    }
+                }
             }
-            float4 v = ld4(y + r * ldy + c);
-            const double gd[4] = {g.x, g.y, g.z, g.w}, vd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                s[k] += gd[k];
-                s2[k] += gd[k] * ((vd[k] - mud[k]) * isd[k]);
+                s[k] += (double)f[k];
+                s2[k] += (double)f2[k];
             }
         }
     }
@@ -218,15 +238,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
 }
 
 // dbeta = sum dz, dgamma = sum dz*xhat; sums[2][C] keeps them in double for stage 2
-template <typename T>
+// block = CPB channels x (256 / CPB) tile lanes
+template <typename T, int CPB>
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const T* __restrict__ partials, int tiles, int C,
                                                          float* dgamma, float* dbeta, double* sums) {
-    __shared__ double red[2][16][17];
-    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    constexpr int TL = 256 / CPB;
+    __shared__ double red[2][TL][CPB + 1];
+    const int cl = threadIdx.x % CPB, tl = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl;
     double s = 0.0, s2 = 0.0;
     if (c < C)
-        for (int k = tl; k < tiles; k += 16) {
+        for (int k = tl; k < tiles; k += TL) {
             s += (double)partials[(size_t)k * C + c];
             s2 += (double)partials[(size_t)(tiles + k) * C + c];
         }
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const T* __restrict__ p
     red[1][tl][cl] = s2;
     __syncthreads();
     if (tl == 0 && c < C) {
-        for (int k = 1; k < 16; ++k) {
+        for (int k = 1; k < TL; ++k) {
             s += red[0][k][cl];
             s2 += red[1][k][cl];
         }
@@ -308,7 +330,9 @@ static int chk_rows(const char* what, int64_t M, int C, int ld) {
 using namespace iswm;
 
 extern "C" int iswm_colstat_tiles(int64_t M) {
-    int64_t t = (M + 255) / 256;
+    // one workgroup per tile (per 256/1024-channel column block): ~32 rows each keeps >= 500 workgroups
+    // in flight on the 33x33 stages (M = 17 424) -- 69 tiles of 256 rows ran at 2.7 TB/s
+    int64_t t = (M + 31) / 32;
     if (t > 1024) t = 1024;
     if (t < 1) t = 1;
     return (int)t;
@@ -405,16 +429,23 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
     {
         RowPlan p = plan_rows(M, C, tiles);
         dim3 grid(p.rowblocks, p.colblocks), blk(256);
-        if (relu)
-            hipLaunchKernelGGL((k_bn_bwd_reduce<true>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C,
-                               mean, invstd, p.CQ, p.RL, tiles, partials);
-        else
-            hipLaunchKernelGGL((k_bn_bwd_reduce<false>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C,
-                               mean, invstd, p.CQ, p.RL, tiles, partials);
+#define RLAUNCH(R, D)                                                                                           \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<R, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean, invstd, \
+                       p.CQ, p.RL, tiles, partials)
+        const bool dbl = M <= 8192;
+        if (relu && dbl) RLAUNCH(true, true);
+        else if (relu) RLAUNCH(true, false);
+        else if (dbl) RLAUNCH(false, true);
+        else RLAUNCH(false, false);
+#undef RLAUNCH
         if (int e = check_launch("bn_bwd_reduce")) return e;
     }
-    hipLaunchKernelGGL((k_bn_bwd_finalize<double>), dim3((C + 15) / 16), dim3(256), 0, s, partials, tiles, C, dgamma,
-                       dbeta, sums);
+    if (tiles > 128)
+        hipLaunchKernelGGL((k_bn_bwd_finalize<double, 4>), dim3((C + 3) / 4), dim3(256), 0, s, partials, tiles, C,
+                           dgamma, dbeta, sums);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_finalize<double, 16>), dim3((C + 15) / 16), dim3(256), 0, s, partials, tiles, C,
+                           dgamma, dbeta, sums);
     if (int e = check_launch("bn_bwd_finalize")) return e;
     RowPlan p = plan_rows(M, C);
     dim3 grid(p.rowblocks, p.colblocks), blk(256);
@@ -441,7 +472,7 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
 extern "C" int iswm_colsum_finalize(const float* partials, int tiles, int C, float* out, float* scratch,
                                     iswm_stream_t stream) {
     ISWM_REQUIRE(partials && out && scratch && tiles > 0 && C > 0, "colsum_finalize: bad argument");
-    hipLaunchKernelGGL((k_bn_bwd_finalize<float>), dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL((k_bn_bwd_finalize<float, 4>), dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials,
                        tiles, C, scratch, out, (double*)nullptr);
     return check_launch("colsum_finalize");
 }

@@ -344,7 +344,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_dgrad(const ConvArgs a) {
 // wgrad:  dw[co, j] = sum_p dy[p, co] * xG[p, j],  j = (kh, kw, ci) flattened, p = (n, oh, ow)
 // Both operands row-contiguous; the pixel axis is split across blockIdx.y into slabs.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN>
+static __device__ __attribute__((aligned(16))) float g_zero_row_w[64];   // target of out-of-bounds rows
+
+// MODE 0: any geometry.  MODE 1: stride 1 and Ho == H, Wo == W ("same" convs: every 3x3 of the net
+// except the two strided ones) -- the gathered pixel of output pixel p is p + dh*W + dw, so addresses
+// advance by a constant and only the bounds test needs (oh, ow).  MODE 2: 1x1 stride 1 -- no bounds.
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
     constexpr int MB = BM / 64, NB = BN / 64;
     constexpr int AQ = BM / 4, AKR = 256 / AQ, APASS = 32 / AKR;
@@ -392,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
         }
     };
     auto advance = [&](int kc) {
+        if (MODE == 2) return;
         if (!fast_adv) {
             decode(kc);
             return;
@@ -432,20 +438,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
     };
 
     float4 ra[APASS], rb[BPASS];
+    // All loads are unconditional: rows past the end of the split / outside the image read the zero row
+    // (B side), and the A side then only needs a valid address (0 x finite = 0), so it clamps its pixel.
+    const float* abase = aok ? a.y + m0 + aq * 4 : g_zero_row_w;
+    const int a_ld = aok ? a.ldy : 0;
+    const int shift = dh * a.W + dw;     // MODE 1/2: input pixel = output pixel + shift
     auto gload = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
-            int p = p_begin + kc * 32 + ak0 + AKR * j;
-            ra[j] = (aok && p < p_end) ? ldg4(a.y + (size_t)p * a.ldy + m0 + aq * 4)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            int p = min(p_begin + kc * 32 + ak0 + AKR * j, P - 1);
+            ra[j] = ldg4(abase + (size_t)p * a_ld);
         }
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
             int p = p_begin + kc * 32 + bk0 + BKR * j;
-            int ih = boh[j] * a.stride + dh, iw = bow[j] * a.stride + dw;
-            bool ok = bok && p < p_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            rb[j] = ok ? ldg4(a.x + (size_t)((bn_[j] * a.H + ih) * a.W + iw) * a.ldx + c4 * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = bok && p < p_end;
+            const float* src;
+            if (MODE == 2) {
+                src = a.x + (size_t)p * a.ldx + c4 * 4;
+            } else if (MODE == 1) {
+                int ih = boh[j] + dh, iw = bow[j] + dw;
+                ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                src = a.x + (size_t)(p + shift) * a.ldx + c4 * 4;
+            } else {
+                int ih = boh[j] * a.stride + dh, iw = bow[j] * a.stride + dw;
+                ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                src = a.x + (size_t)((bn_[j] * a.H + ih) * a.W + iw) * a.ldx + c4 * 4;
+            }
+            rb[j] = ldg4(ok ? src : g_zero_row_w);
         }
     };
     auto lstore = [&](int buf) {
@@ -599,14 +619,27 @@ static WgradPlan plan_wgrad(const iswm_conv_desc* d) {
     p.NT = (Ktot + p.bn - 1) / p.bn;
     const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
     const int64_t tiles = (int64_t)p.MT * p.NT;
-    int64_t want = (1024 + tiles - 1) / tiles;         // ~4 workgroups per CU in total
-    int64_t maxs = (P + 255) / 256;                    // at least 256 pixels per split
-    if (want > maxs) want = maxs;
-    if (want < 1) want = 1;
-    int64_t ps = (P + want - 1) / want;
-    ps = (ps + 31) / 32 * 32;
-    p.psplit = (int)ps;
-    p.nsplit = (int)((P + ps - 1) / ps);
+    // Split count: minimise  rounds x (chunks per workgroup) x chunk time  +  slab write/read time, where a
+    // round is 512 co-resident workgroups (2 per CU) and a 128x128x32 chunk takes ~4.5 us when two
+    // workgroups share a CU.  tiles*splits just above a multiple of 512 costs a whole extra round.
+    const double chunk_us = 4.5 * (double)(p.bm * p.bn) / 16384.0;
+    const double slab_us = (double)d->Cout * Ktot * 8.0 / 4.0e6;   // one slab written + read at ~4 TB/s
+    int64_t maxs = (P + 255) / 256;                                 // at least 256 pixels per split
+    if (maxs > 64) maxs = 64;
+    double best = 1e300;
+    p.psplit = (int)((P + 31) / 32 * 32);
+    p.nsplit = 1;
+    for (int64_t ns = 1; ns <= maxs; ++ns) {
+        int64_t ps = ((P + ns - 1) / ns + 31) / 32 * 32;
+        int64_t nsp = (P + ps - 1) / ps;
+        int64_t rounds = (tiles * nsp + 511) / 512;
+        double t = (double)rounds * (double)(ps / 32 + 3) * chunk_us + (nsp > 1 ? (double)nsp * slab_us + 5.0 : 0.0);
+        if (t < best) {
+            best = t;
+            p.psplit = (int)ps;
+            p.nsplit = (int)nsp;
+        }
+    }
     return p;
 }
 
@@ -635,7 +668,9 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         }
     } else {
         WgradPlan p = plan_wgrad(d);
-        snprintf(buf, buflen, "k_conv_wgrad<%d, %d>", p.bm, p.bn);
+        const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
+        const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
+        snprintf(buf, buflen, "k_conv_wgrad<%d, %d, %d>", p.bm, p.bn, mode);
     }
     return 0;
 }
@@ -721,10 +756,17 @@ extern "C" int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const 
     a.stats = (p.nsplit > 1) ? workspace : dw;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.MT * p.NT, p.nsplit);
-    if (p.bm == 128)
-        hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((k_conv_wgrad<64, 64>), grid, dim3(256), 0, s, a);
+    const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
+    const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
+#define WLAUNCH(BM_, BN_)                                                                       \
+    do {                                                                                        \
+        if (mode == 2) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 2>), grid, dim3(256), 0, s, a);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 1>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 0>), grid, dim3(256), 0, s, a);                \
+    } while (0)
+    if (p.bm == 128) WLAUNCH(128, 128);
+    else WLAUNCH(64, 64);
+#undef WLAUNCH
     if (int e = check_launch("conv_wgrad")) return e;
     if (p.nsplit > 1) {
         int64_t n4 = (int64_t)d->Cout * a.Ktot / 4;

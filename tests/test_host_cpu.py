@@ -37,7 +37,7 @@ def test_stat_tile_queries_are_pure_host_functions():
     assert rows in (64, 128) and lib.iswm_conv2d_stat_tiles(ctypes.byref(d)) == (16 * 33 * 33 + rows - 1) // rows
     assert lib.iswm_conv2d_wgrad_workspace(ctypes.byref(d)) % (256 * 9 * 2048 * 4) == 0
     assert lib.iswm_colstat_tiles(1) == 1 and lib.iswm_colstat_tiles(10 ** 7) == 1024
-    assert lib.iswm_colstat_tile_rows(578) == 193 and lib.iswm_colstat_tile_rows(1) == 1
+    assert lib.iswm_colstat_tile_rows(578) == 31 and lib.iswm_colstat_tile_rows(1) == 1
     assert lib.iswm_loss_blocks(513 * 513 * 16) == 1024
 
 
