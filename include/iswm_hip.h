@@ -49,6 +49,14 @@ typedef struct {
     int ldy;            /* pixel pitch of y  (floats) */
 } iswm_conv_desc;
 
+/* Arithmetic of the convolution kernels: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
+ * 1 = "bf16x6": each fp32 operand is split exactly into three bf16 pieces and the product is formed
+ * from six bf16 MFMAs with fp32 accumulation (error ~1e-7 relative, i.e. fp32 level, at up to 2.7x the
+ * fp32 MFMA rate).  Default 1; the environment variable ISWM_CONV_MATH=f32 selects 0 at load time.
+ * Geometries the bf16x6 kernels do not cover (gathered channel count not a multiple of 32: the stem, the
+ * 304-channel decoder input) always run on the fp32 MFMA kernels. */
+int iswm_set_conv_math(int mode);
+int iswm_get_conv_math(void);
 /* name of the device kernel a call with this geometry launches (kind 0 fwd, 1 dgrad, 2 wgrad) --
  * lets a profiler label its timings with the symbol rocprofv3 reports */
 int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen);
@@ -65,6 +73,13 @@ int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const float* w, con
  * accumulate != 0 adds into dx (branches that share an input, residual joins) */
 int iswm_conv2d_dgrad(const iswm_conv_desc* d, const float* dy, const float* w, float* dx,
                       int accumulate, iswm_stream_t stream);
+/* bf16x6 data gradient: needs the weights transposed to [Cin][KH][KW][Cout] (K axis contiguous for the
+ * matrix cores).  iswm_conv2d_dgrad_wants_wt tells the host when to use this pair instead of
+ * iswm_conv2d_dgrad (current conv math is bf16x6 and Cout % 32 == 0). */
+int iswm_transpose_weights(const iswm_conv_desc* d, const float* w, float* wt, iswm_stream_t stream);
+int iswm_conv2d_dgrad_wants_wt(const iswm_conv_desc* d);
+int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, const float* wt, float* dx, int accumulate,
+                         iswm_stream_t stream);
 /* dw[Cout][KH][KW][Cin] = sum over pixels.  workspace holds split-K slabs. */
 size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d);
 int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -23,11 +23,16 @@ _SIGS = {
     # name: (restype, [argtypes])
     "iswm_last_error": (c_char_p, []),
     "iswm_version": (c_int, []),
+    "iswm_set_conv_math": (c_int, [c_int]),
+    "iswm_get_conv_math": (c_int, []),
     "iswm_conv2d_kernel_name": (c_int, [POINTER(ConvDesc), c_int, c_char_p, c_int]),
     "iswm_conv2d_stat_tile_rows": (c_int, [POINTER(ConvDesc)]),
     "iswm_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
     "iswm_conv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "iswm_conv2d_dgrad": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
+    "iswm_transpose_weights": (c_int, [POINTER(ConvDesc), P, P, P]),
+    "iswm_conv2d_dgrad_wants_wt": (c_int, [POINTER(ConvDesc)]),
+    "iswm_conv2d_dgrad_wt": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
     "iswm_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "iswm_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
     "iswm_colstat_tiles": (c_int, [c_int64]),

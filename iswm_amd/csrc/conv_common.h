@@ -31,6 +31,40 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 constexpr int KC_PITCH = 36;  // floats per LDS row of a K-contiguous operand tile (32 + 4 pad)
 
 
+// ---- bf16x6 helpers (see conv_mfma_x6.hip) ------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                   0, 0, 0);
+}
+
+// exact 3-way truncation split of 4 floats into packed bf16x4 planes
+__device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned xb = __float_as_uint(x[i]);
+        float r1 = x[i] - __uint_as_float(xb & 0xFFFF0000u);
+        unsigned rb = __float_as_uint(r1);
+        float r2 = r1 - __uint_as_float(rb & 0xFFFF0000u);
+        h[i] = xb;
+        m[i] = rb;
+        l[i] = __float_as_uint(r2);
+    }
+    // pack the upper halves of two words: {src0 = odd element, src1 = even element}
+    hi = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    mid = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+
+
+// bf16x6 path (conv_mfma_x6.hip): fp32-accurate products from six bf16 MFMAs
+bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn);
+bool launch_conv_dgrad_x6(ConvArgs a, hipStream_t s, int bm, int bn);
+void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s);
+
 // tap-uniform fast path (conv_mfma_u.hip); each returns false when the geometry does not qualify
 bool launch_conv_fwd_u(ConvArgs a, hipStream_t s);
 void conv_pick_tile(int64_t M, int cols, int* bm, int* bn);

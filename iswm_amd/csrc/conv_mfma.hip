@@ -24,6 +24,9 @@
 //     the training-mode BatchNorm that follows every conv (deterministic two-stage stats);
 //   * wgrad flattens (tap, cin) into the GEMM N axis and splits the pixel (K) axis across
 //     workgroups into slabs that a second kernel sums in a fixed order (bit-reproducible).
+#include <stdlib.h>
+#include <string.h>
+
 #include "conv_common.h"
 
 namespace iswm {
@@ -349,14 +352,24 @@ static __device__ __attribute__((aligned(16))) float g_zero_row_w[64];   // targ
 // MODE 0: any geometry.  MODE 1: stride 1 and Ho == H, Wo == W ("same" convs: every 3x3 of the net
 // except the two strided ones) -- the gathered pixel of output pixel p is p + dh*W + dw, so addresses
 // advance by a constant and only the bounds test needs (oh, ow).  MODE 2: 1x1 stride 1 -- no bounds.
-template <int BM, int BN, int MODE>
+// X6: bf16x6 arithmetic (conv_mfma_x6.hip).  Both operands arrive with the GEMM K axis (pixels) STRIDED in
+// memory, so the three bf16 planes are kept [k][row] in LDS (natural 8-byte writes) and the k-contiguous MFMA
+// fragments are produced by gfx950's transposing LDS read ds_read_b64_tr_b16 (4 k x 16 rows per 16 lanes);
+// row pitch 2*rows + 64 B puts the 4 k-rows of one read on disjoint bank quarters.
+template <int BM, int BN, int MODE, bool X6>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
     constexpr int MB = BM / 64, NB = BN / 64;
     constexpr int AQ = BM / 4, AKR = 256 / AQ, APASS = 32 / AKR;
     constexpr int BQ = BN / 4, BKR = 256 / BQ, BPASS = 32 / BKR;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * (BM + BN)];
+    constexpr int XPA = BM * 2 + 64, XPB = BN * 2 + 64;              // X6 row pitches (bytes)
+    constexpr int XPLA = 32 * XPA, XPLB = 32 * XPB;                  // X6 plane sizes (bytes)
+    constexpr int SMEM_BYTES = X6 ? 3 * (XPLA + XPLB) : 2 * 32 * (BM + BN) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+    float* smem = reinterpret_cast<float*>(smem_raw);
     float* As = smem;
     float* Bs = smem + 2 * 32 * BM;
+    unsigned char* Ax = smem_raw;               // X6: [3][32][XPA]
+    unsigned char* Bx = smem_raw + 3 * XPLA;    // X6: [3][32][XPB]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -469,12 +482,33 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
         }
     };
     auto lstore = [&](int buf) {
+        if constexpr (X6) {
 #pragma unroll
-        for (int j = 0; j < APASS; ++j)
-            *reinterpret_cast<float4*>(&As[(buf * 32 + ak0 + AKR * j) * BM + aq * 4]) = ra[j];
+            for (int j = 0; j < APASS; ++j) {
+                uint2 h, m, l;
+                split3(ra[j], h, m, l);
+                unsigned char* p = Ax + (ak0 + AKR * j) * XPA + aq * 8;
+                *reinterpret_cast<uint2*>(p) = h;
+                *reinterpret_cast<uint2*>(p + XPLA) = m;
+                *reinterpret_cast<uint2*>(p + 2 * XPLA) = l;
+            }
 #pragma unroll
-        for (int j = 0; j < BPASS; ++j)
-            *reinterpret_cast<float4*>(&Bs[(buf * 32 + bk0 + BKR * j) * BN + bq * 4]) = rb[j];
+            for (int j = 0; j < BPASS; ++j) {
+                uint2 h, m, l;
+                split3(rb[j], h, m, l);
+                unsigned char* p = Bx + (bk0 + BKR * j) * XPB + bq * 8;
+                *reinterpret_cast<uint2*>(p) = h;
+                *reinterpret_cast<uint2*>(p + XPLB) = m;
+                *reinterpret_cast<uint2*>(p + 2 * XPLB) = l;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < APASS; ++j)
+                *reinterpret_cast<float4*>(&As[(buf * 32 + ak0 + AKR * j) * BM + aq * 4]) = ra[j];
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j)
+                *reinterpret_cast<float4*>(&Bs[(buf * 32 + bk0 + BKR * j) * BN + bq * 4]) = rb[j];
+        }
     };
 
     f32x16 acc[MB][NB];
@@ -499,41 +533,98 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
             if (!skip(kc)) return true;
         }
     };
-    bool more = next();
-    if (more) {
-        gload(kc);
-        lstore(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    while (more) {
-        const bool more2 = next();
-        if (more2) gload(kc);
-        const float* Ab = &As[(cur * 32 + lh * 4) * BM + wm * (BM / 2) + li];
-        const float* Bb = &Bs[(cur * 32 + lh * 4) * BN + wn * (BN / 2) + li];
+    if constexpr (X6) {
+        // transposing-read lane roles: 16-lane group g = lane>>4 covers rows 16*(g&1).. of the 32-row MFMA tile
+        // for k half h = g>>1; lane 4q+p of the group addresses k-row q, columns 4p..4p+3
+        const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+        const int th = tg >> 1, tc = (tg & 1) * 16 + tp * 4;
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        auto tr_frag = [&](const unsigned char* plane, int pitch, int col0, int ks) -> uint4 {
+            const unsigned char* p = plane + (ks * 16 + th * 8 + tq) * pitch + (col0 + tc) * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * pitch));
+            uint2 a2 = __builtin_bit_cast(uint2, lo), b2 = __builtin_bit_cast(uint2, hi);
+            return make_uint4(a2.x, a2.y, b2.x, b2.y);
+        };
+        bool more = next();
+        if (more) gload(kc);
+        while (more) {
+            lstore(0);
+            __syncthreads();
+            const bool more2 = next();
+            if (more2) gload(kc);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float af[MB][4], bf[NB][4];
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 ah[MB], am[MB], al[MB], bh[NB], bm[NB], bl[NB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int c0 = wm * (BM / 2) + mb * 32;
+                    ah[mb] = tr_frag(Ax, XPA, c0, ks);
+                    am[mb] = tr_frag(Ax + XPLA, XPA, c0, ks);
+                    al[mb] = tr_frag(Ax + 2 * XPLA, XPA, c0, ks);
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) af[mb][j] = Ab[(g * 8 + j) * BM + mb * 32];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bf[nb][j] = Bb[(g * 8 + j) * BN + nb * 32];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c0 = wn * (BN / 2) + nb * 32;
+                    bh[nb] = tr_frag(Bx, XPB, c0, ks);
+                    bm[nb] = tr_frag(Bx + XPLB, XPB, c0, ks);
+                    bl[nb] = tr_frag(Bx + 2 * XPLB, XPB, c0, ks);
+                }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[mb][nb] = mfma32(af[mb][j], bf[nb][j], acc[mb][nb]);
+                    for (int nb = 0; nb < NB; ++nb) {
+                        f32x16 c = acc[mb][nb];
+                        c = mfma_bf16(al[mb], bh[nb], c);
+                        c = mfma_bf16(ah[mb], bl[nb], c);
+                        c = mfma_bf16(am[mb], bm[nb], c);
+                        c = mfma_bf16(am[mb], bh[nb], c);
+                        c = mfma_bf16(ah[mb], bm[nb], c);
+                        c = mfma_bf16(ah[mb], bh[nb], c);
+                        acc[mb][nb] = c;
+                    }
+            }
+            __syncthreads();
+            more = more2;
         }
-        if (more2) lstore(cur ^ 1);
+    } else {
+        bool more = next();
+        if (more) {
+            gload(kc);
+            lstore(0);
+        }
         __syncthreads();
-        cur ^= 1;
-        more = more2;
+        int cur = 0;
+        while (more) {
+            const bool more2 = next();
+            if (more2) gload(kc);
+            const float* Ab = &As[(cur * 32 + lh * 4) * BM + wm * (BM / 2) + li];
+            const float* Bb = &Bs[(cur * 32 + lh * 4) * BN + wn * (BN / 2) + li];
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float af[MB][4], bf[NB][4];
+    #pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) af[mb][j] = Ab[(g * 8 + j) * BM + mb * 32];
+    #pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) bf[nb][j] = Bb[(g * 8 + j) * BN + nb * 32];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+    #pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = mfma32(af[mb][j], bf[nb][j], acc[mb][nb]);
+            }
+            if (more2) lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+            more = more2;
+        }
     }
     float* out = a.stats + (size_t)split * a.Cout * a.Ktot;  // slab (or dw itself when nsplit == 1)
 #pragma unroll
@@ -647,6 +738,22 @@ static WgradPlan plan_wgrad(const iswm_conv_desc* d) {
 
 using namespace iswm;
 
+// 0: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32);  1 (default): bf16x6 split on the bf16 matrix cores
+static int g_conv_math = -1;
+static int conv_math() {
+    if (g_conv_math < 0) {
+        const char* e = getenv("ISWM_CONV_MATH");
+        g_conv_math = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;   // default: bf16x6
+    }
+    return g_conv_math;
+}
+extern "C" int iswm_set_conv_math(int mode) {
+    ISWM_REQUIRE(mode == 0 || mode == 1, "set_conv_math: mode must be 0 (f32) or 1 (bf16x6)");
+    g_conv_math = mode;
+    return 0;
+}
+extern "C" int iswm_get_conv_math(void) { return conv_math(); }
+
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
     ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 2, "kernel_name: bad argument");
     int bm, bn;
@@ -654,7 +761,7 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
         if (d->Cin % 32 == 0) {
             conv_pick_tile(M, d->Cout, &bm, &bn);
-            snprintf(buf, buflen, "k_conv_fwd_u<%d, %d>", bm, bn);
+            snprintf(buf, buflen, conv_math() == 1 ? "k_conv_x6<%d, %d, false>" : "k_conv_fwd_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_fwd<%d>", use_narrow_tile((M + 127) / 128, d->Cout) ? 64 : 128);
         }
@@ -662,7 +769,8 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         const int64_t M = (int64_t)d->N * d->H * d->W;
         if (d->Cout % 32 == 0) {
             conv_pick_tile(M, d->Cin, &bm, &bn);
-            snprintf(buf, buflen, "k_conv_dgrad_u<%d, %d>", bm, bn);
+            if (conv_math() == 1) snprintf(buf, buflen, "k_conv_x6<%d, %d, true>", bm, bn);
+            else snprintf(buf, buflen, "k_conv_dgrad_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_dgrad<%d>", use_narrow_tile((M + 127) / 128, d->Cin) ? 64 : 128);
         }
@@ -670,7 +778,7 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         WgradPlan p = plan_wgrad(d);
         const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
         const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
-        snprintf(buf, buflen, "k_conv_wgrad<%d, %d, %d>", p.bm, p.bn, mode);
+        snprintf(buf, buflen, "k_conv_wgrad<%d, %d, %d, %s>", p.bm, p.bn, mode, conv_math() == 1 ? "true" : "false");
     }
     return 0;
 }
@@ -697,6 +805,11 @@ extern "C" int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const fl
     a.Ktot = d->KH * d->KW * d->Cin;
     a.MT = (a.M + 127) / 128;
     hipStream_t s = (hipStream_t)stream;
+    if (conv_math() == 1 && d->Cin % 32 == 0) {
+        int bm, bn;
+        conv_pick_tile(a.M, d->Cout, &bm, &bn);
+        if (launch_conv_fwd_x6(a, s, bm, bn)) return check_launch("conv_fwd_x6");
+    }
     if (launch_conv_fwd_u(a, s)) return check_launch("conv_fwd_u");
     if (use_narrow_tile(a.MT, d->Cout)) {
         a.NT = (d->Cout + 63) / 64;
@@ -732,6 +845,36 @@ extern "C" int iswm_conv2d_dgrad(const iswm_conv_desc* d, const float* dy, const
     return check_launch("conv_dgrad");
 }
 
+extern "C" int iswm_transpose_weights(const iswm_conv_desc* d, const float* w, float* wt, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(w && wt && w != wt, "transpose_weights: bad pointer");
+    launch_transpose_ohwi(w, wt, d->Cout, d->KH * d->KW, d->Cin, (hipStream_t)stream);
+    return check_launch("transpose_weights");
+}
+
+/* 1 when iswm_conv2d_dgrad_wt (bf16x6 data gradient on transposed weights) applies to this geometry under
+ * the current conv math */
+extern "C" int iswm_conv2d_dgrad_wants_wt(const iswm_conv_desc* d) {
+    return (d && conv_math() == 1 && d->Cout % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, const float* wt, float* dx,
+                                    int accumulate, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(dy && wt && dx, "conv_dgrad_wt: null pointer");
+    ISWM_REQUIRE(aligned16(dy) && aligned16(wt) && aligned16(dx), "conv_dgrad_wt: pointers must be 16-byte aligned");
+    ISWM_REQUIRE(d->Cout % 32 == 0, "conv_dgrad_wt: Cout must be a multiple of 32");
+    ConvArgs a = base_args(d);
+    a.x = dy; a.w = wt; a.y = dx; a.accumulate = accumulate;
+    a.ldx = d->ldy; a.ldy = d->ldx;
+    a.M = d->N * d->H * d->W;
+    a.Ktot = d->KH * d->KW * d->Cout;
+    int bm, bn;
+    conv_pick_tile(a.M, d->Cin, &bm, &bn);
+    launch_conv_dgrad_x6(a, (hipStream_t)stream, bm, bn);
+    return check_launch("conv_dgrad_x6");
+}
+
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
     WgradPlan p = plan_wgrad(d);
@@ -758,14 +901,17 @@ extern "C" int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const 
     dim3 grid(p.MT * p.NT, p.nsplit);
     const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
     const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
-#define WLAUNCH(BM_, BN_)                                                                       \
-    do {                                                                                        \
-        if (mode == 2) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 2>), grid, dim3(256), 0, s, a);      \
-        else if (mode == 1) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 1>), grid, dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 0>), grid, dim3(256), 0, s, a);                \
+    const bool x6 = conv_math() == 1;
+#define WLAUNCH(BM_, BN_, X_)                                                                         \
+    do {                                                                                              \
+        if (mode == 2) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 2, X_>), grid, dim3(256), 0, s, a);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 1, X_>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 0, X_>), grid, dim3(256), 0, s, a);                \
     } while (0)
-    if (p.bm == 128) WLAUNCH(128, 128);
-    else WLAUNCH(64, 64);
+    if (p.bm == 128 && x6) WLAUNCH(128, 128, true);
+    else if (p.bm == 128) WLAUNCH(128, 128, false);
+    else if (x6) WLAUNCH(64, 64, true);
+    else WLAUNCH(64, 64, false);
 #undef WLAUNCH
     if (int e = check_launch("conv_wgrad")) return e;
     if (p.nsplit > 1) {

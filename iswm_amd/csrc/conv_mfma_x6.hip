@@ -1,0 +1,314 @@
+// fp32-accurate implicit-GEMM convolution on the BF16 matrix cores ("bf16x6").
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  An fp32 value splits EXACTLY into three
+// bf16 pieces by truncation (24-bit significand = 8 + 8 + 8 bits):  x = hi + mid + lo.  A product then is
+//   a*b = ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm   + O(2^-24 |a*b|)
+// i.e. six bf16 MFMAs (products of bf16 pairs are exact in fp32, accumulation is fp32) reproduce the fp32
+// product to ~1.2e-7 relative -- the rounding level of fp32 itself -- at 16/6 = 2.7x the fp32 MFMA rate.
+// The dropped terms (am*bl, al*bm, al*bl) are below 2^-24 of the product.
+//
+// Structure = conv_mfma_u.hip (tap-uniform K loop, pointer/stride gather, padding-tap culling), except:
+//   * the loader splits each staged float4 into three packed bf16x4 (4 VALU ops per element + 3 v_perm per
+//     pair) and writes three bf16 planes to LDS: [plane][row][32 k] with an 80-byte row pitch, which makes
+//     the 16-byte fragment reads of v_mfma_f32_32x32x16_bf16 (lane r = l&31, h = l>>5 reads k = 8h..8h+7 of
+//     row r) bank-conflict free (5r mod 16 is a permutation);
+//   * LDS holds ONE K chunk (3 planes x 2 operands x 128 rows x 80 B = 61 KB -> 2 workgroups per CU); the next
+//     chunk is prefetched into registers while the current one is multiplied (two barriers per chunk).
+#include "conv_common.h"
+
+namespace iswm {
+
+static __device__ __attribute__((aligned(16))) float g_zero_row_x[64];
+
+constexpr int X6_PITCH = 80;   // bytes per LDS row of one bf16 plane (32 k x 2 B + 16 B pad)
+
+// DGRAD == false: forward.  rows = output pixels, A = x gathered per tap, B = OHWI weights [cout][(tap, cin)].
+// DGRAD == true : data gradient.  rows = INPUT pixels, A = dy gathered per tap (a.x = dy, pitch a.ldx),
+//                 B = TRANSPOSED weights [cin][(tap, cout)] (iswm_transpose_weights), output a.y = dx.
+// In both cases the GEMM K axis (tap, gathered channel) is contiguous in memory for A and B.
+template <int BM, int BN, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void k_conv_x6(const ConvArgs a) {
+    const int GC = DGRAD ? a.Cout : a.Cin;     // channels of the gathered operand (per tap)
+    const int NC = DGRAD ? a.Cin : a.Cout;     // output columns
+    constexpr int MB = BM / 64, NB = BN / 64, AR = BM / 32, BR = BN / 32;
+    constexpr int PLANE_A = BM * X6_PITCH, PLANE_B = BN * X6_PITCH;          // bytes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (PLANE_A + PLANE_B)];
+    unsigned char* As = smem;                 // [3][BM][80 B]
+    unsigned char* Bs = smem + 3 * PLANE_A;   // [3][BN][80 B]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L / a.NT, nt = L - mt * a.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int q = t & 7, r0 = t >> 3;
+
+    // row -> pixel of the tensor the rows live in (fwd: output Ho x Wo; dgrad: input H x W)
+    const int RH = DGRAD ? a.H : a.Ho, RW = DGRAD ? a.W : a.Wo;
+    const int GH = DGRAD ? a.Ho : a.H, GW = DGRAD ? a.Wo : a.W;     // gathered tensor dims
+    const int RHW = RH * RW;
+    int ihb[AR], iwb[AR], pb[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        int m = m0 + r0 + 32 * j;
+        if (m < a.M) {
+            int n = m / RHW, rem = m - n * RHW;
+            int rh = rem / RW, rw = rem - rh * RW;
+            ihb[j] = DGRAD ? rh + a.pad : rh * a.stride - a.pad;
+            iwb[j] = DGRAD ? rw + a.pad : rw * a.stride - a.pad;
+            pb[j] = n * GH * GW;
+        } else {
+            ihb[j] = -(1 << 28);
+            iwb[j] = 0;
+            pb[j] = 0;
+        }
+    }
+    const float* wbase[BR];
+    bool wok[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        int n = n0 + r0 + 32 * j;
+        wok[j] = n < NC;
+        wbase[j] = a.w + (size_t)(wok[j] ? n : 0) * a.Ktot + q * 4;
+    }
+    const int taps = a.KH * a.KW;
+    const int nCC = GC >> 5;
+
+    const float* aptr[AR];
+    int astep[AR];
+    const float* bptr[BR];
+    int bstep[BR];
+    auto setup_tap = [&](int tap) -> bool {
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int dh = kh * a.dil, dw = kw * a.dil;
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            int gh, gw;
+            bool ok;
+            if (DGRAD) {
+                int th = ihb[j] - dh, tw = iwb[j] - dw;
+                gh = th;
+                gw = tw;
+                ok = th >= 0 && tw >= 0;
+                if (a.stride != 1) {
+                    gh = th / a.stride;
+                    gw = tw / a.stride;
+                    ok = ok && (gh * a.stride == th) && (gw * a.stride == tw);
+                }
+                ok = ok && gh < GH && gw < GW;
+            } else {
+                gh = ihb[j] + dh;
+                gw = iwb[j] + dw;
+                ok = (unsigned)gh < (unsigned)GH && (unsigned)gw < (unsigned)GW;
+            }
+            aptr[j] = ok ? a.x + (size_t)(pb[j] + gh * GW + gw) * a.ldx + q * 4 : g_zero_row_x + q * 4;
+            astep[j] = ok ? 32 : 0;
+            any |= ok;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            bptr[j] = wok[j] ? wbase[j] + (size_t)tap * GC : g_zero_row_x + q * 4;
+            bstep[j] = wok[j] ? 32 : 0;
+        }
+        return __syncthreads_or(any) != 0;
+    };
+    int tap = -1, cc = nCC - 1;
+    auto next = [&]() -> bool {
+        if (++cc < nCC) return true;
+        cc = 0;
+        do {
+            if (++tap >= taps) return false;
+        } while (!setup_tap(tap));
+        return true;
+    };
+
+    float4 ra[AR], rb[BR];
+    auto gload = [&]() {
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            ra[j] = ldg4(aptr[j]);
+            aptr[j] += astep[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            rb[j] = ldg4(bptr[j]);
+            bptr[j] += bstep[j];
+        }
+    };
+    auto lstore = [&]() {   // split into bf16 planes and write 8 B per plane per row
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            uint2 h, m, l;
+            split3(ra[j], h, m, l);
+            unsigned char* p = As + (r0 + 32 * j) * X6_PITCH + q * 8;
+            *reinterpret_cast<uint2*>(p) = h;
+            *reinterpret_cast<uint2*>(p + PLANE_A) = m;
+            *reinterpret_cast<uint2*>(p + 2 * PLANE_A) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            uint2 h, m, l;
+            split3(rb[j], h, m, l);
+            unsigned char* p = Bs + (r0 + 32 * j) * X6_PITCH + q * 8;
+            *reinterpret_cast<uint2*>(p) = h;
+            *reinterpret_cast<uint2*>(p + PLANE_B) = m;
+            *reinterpret_cast<uint2*>(p + 2 * PLANE_B) = l;
+        }
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bool more = next();
+    if (more) gload();
+    while (more) {
+        lstore();
+        __syncthreads();
+        const bool more2 = next();
+        if (more2) gload();
+        // fragment base: row (wave tile row + lane&31), k offset 8*(lane>>5) elements = 16 B
+        const unsigned char* Ab = As + (wm * (BM / 2) + li) * X6_PITCH + lh * 16;
+        const unsigned char* Bb = Bs + (wn * (BN / 2) + li) * X6_PITCH + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 ah[MB], am[MB], al[MB], bh[NB], bm[NB], bl[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const unsigned char* p = Ab + mb * 32 * X6_PITCH + ks * 32;
+                ah[mb] = *reinterpret_cast<const uint4*>(p);
+                am[mb] = *reinterpret_cast<const uint4*>(p + PLANE_A);
+                al[mb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_A);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const unsigned char* p = Bb + nb * 32 * X6_PITCH + ks * 32;
+                bh[nb] = *reinterpret_cast<const uint4*>(p);
+                bm[nb] = *reinterpret_cast<const uint4*>(p + PLANE_B);
+                bl[nb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_B);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x16 c = acc[mb][nb];
+                    c = mfma_bf16(al[mb], bh[nb], c);     // smallest terms first
+                    c = mfma_bf16(ah[mb], bl[nb], c);
+                    c = mfma_bf16(am[mb], bm[nb], c);
+                    c = mfma_bf16(am[mb], bh[nb], c);
+                    c = mfma_bf16(ah[mb], bm[nb], c);
+                    c = mfma_bf16(ah[mb], bh[nb], c);
+                    acc[mb][nb] = c;
+                }
+        }
+        __syncthreads();
+        more = more2;
+    }
+
+    // ---- epilogue: identical C/D map to the fp32 kernels
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = n0 + wn * (BN / 2) + nb * 32 + li;
+        const bool cok = col < NC;
+        const float bv = (!DGRAD && a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < a.M) {
+                    float* o = &a.y[(size_t)row * a.ldy + col];
+                    *o = (DGRAD && a.accumulate) ? *o + acc[mb][nb][r] : acc[mb][nb][r] + bv;
+                }
+            }
+    }
+    if (!DGRAD && a.stats != nullptr) {
+        float* red = reinterpret_cast<float*>(smem);  // [4][BN]
+        const int cnt = min(BM, a.M - m0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[mb][nb][r];
+            s += __shfl_xor(s, 32);
+            if (lh == 0) red[wm * BN + wn * (BN / 2) + nb * 32 + li] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int c = wn * (BN / 2) + nb * 32 + li;
+            const float mean = (red[c] + red[BN + c]) / (float)cnt;
+            float qv = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float dv = acc[mb][nb][r] - mean;
+                    qv += row < a.M ? dv * dv : 0.f;
+                }
+            qv += __shfl_xor(qv, 32);
+            if (lh == 0) red[(2 + wm) * BN + c] = qv;
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < a.Cout) {
+            a.stats[(size_t)mt * a.Cout + n0 + t] = red[t] + red[BN + t];
+            a.stats[(size_t)(a.MT + mt) * a.Cout + n0 + t] = red[2 * BN + t] + red[3 * BN + t];
+        }
+    }
+}
+
+bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn) {
+    if (a.Cin % 32 != 0) return false;
+    a.MT = (a.M + bm - 1) / bm;
+    a.NT = (a.Cout + bn - 1) / bn;
+    dim3 grid(a.MT * a.NT), blk(256);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_x6<128, 128, false>), grid, blk, 0, s, a);
+    else if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, false>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_conv_x6<64, 64, false>), grid, blk, 0, s, a);
+    return true;
+}
+
+// a: as prepared by iswm_conv2d_dgrad (a.x = dy with pitch a.ldx, a.y = dx with pitch a.ldy, a.M = N*H*W),
+// a.w = TRANSPOSED weights [Cin][taps][Cout]
+bool launch_conv_dgrad_x6(ConvArgs a, hipStream_t s, int bm, int bn) {
+    if (a.Cout % 32 != 0) return false;
+    a.MT = (a.M + bm - 1) / bm;
+    a.NT = (a.Cin + bn - 1) / bn;
+    dim3 grid(a.MT * a.NT), blk(256);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_x6<128, 128, true>), grid, blk, 0, s, a);
+    else if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, true>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_conv_x6<64, 64, true>), grid, blk, 0, s, a);
+    return true;
+}
+
+// wt[ci][t][co] = w[co][t][ci]: per tap a [Cout x Cin] -> [Cin x Cout] transpose through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void k_transpose_ohwi(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                                        int T, int Cin) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + t) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((size_t)ci * T + t) * Cout + co] = tile[tx][r];
+    }
+}
+
+void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s) {
+    dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, T);
+    hipLaunchKernelGGL(k_transpose_ohwi, grid, dim3(256), 0, s, w, wt, Cout, T, Cin);
+}
+
+}  // namespace iswm

@@ -182,6 +182,15 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
         dx = new_act(*x_like_shape, dy.device)
     ldx = geom(dx)[4]
     d = g.desc(ldx, ldy)
+    if _lib.load().iswm_conv2d_dgrad_wants_wt(ctypes.byref(d)):
+        # bf16x6 math: the matrix cores want the K axis (tap, cout) contiguous -> transposed weights
+        wt = torch.empty((g.cin, g.kh, g.kw, g.cout), dtype=torch.float32, device=dy.device)
+        call("iswm_transpose_weights", ctypes.byref(d), _p(w_ohwi), _p(wt), _stream())
+        t0 = KPROF.begin() if KPROF is not None else None
+        call("iswm_conv2d_dgrad_wt", ctypes.byref(d), _p(dy), _p(wt), _p(dx), int(bool(accumulate)), _stream())
+        if t0 is not None:
+            KPROF.end(_kernel_name(d, 1), t0, g.flops(), g.tag())
+        return dx
     t0 = KPROF.begin() if KPROF is not None else None
     call("iswm_conv2d_dgrad", ctypes.byref(d), _p(dy), _p(w_ohwi), _p(dx), int(bool(accumulate)), _stream())
     if t0 is not None:

@@ -30,6 +30,17 @@ from tests.util import RTOL, check, check_grad_robust, check_robust, load, rel_e
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 0], ids=["bf16x6", "f32mfma"], autouse=True)
+def conv_math(request):
+    """every module/model parity test runs under both conv arithmetics (default bf16x6, and exact fp32 MFMA)"""
+    from iswm_amd import _lib
+    lib = _lib.load()
+    old = lib.iswm_get_conv_math()
+    lib.iswm_set_conv_math(request.param)
+    yield request.param
+    lib.iswm_set_conv_math(old)
+
+
 def dev():
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU; the product has no CPU path")
