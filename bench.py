@@ -27,6 +27,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense
+# bf16x6 kernels issue six bf16 MFMAs per fp32 multiply-accumulate, so their roof in ALGORITHMIC fp32
+# FLOP/s is the bf16 dense peak / 6
+X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+
+
+# HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+# correction + WRITE_SIZE), see profiles/ -- filled in when a PMC profile of that kernel has been collected
+TRAFFIC_BYTES_PER_LAUNCH = {
+    # profiles/r01_pmc/wgrad_x6_layer3_3x3_{fetch,write}.csv: layer3 3x3 256->256 @33x33 batch 16 (22 of this
+    # kernel's 33 launches per step): FETCH_SIZE 109.2 MB x 2 (gfx950 wide-read correction) + WRITE_SIZE 32.3 MB
+    # vs 35.7 MB of operands + 33.0 MB of split-K slabs algorithmically (dy/x panels are re-read per tile pair)
+    "k_conv_wgrad<128, 128, 1, true>+reduce": 250.7e6,
+}
 
 
 def parse():
@@ -40,6 +54,9 @@ def parse():
     ap.add_argument("--size", type=int, default=513)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--conv-math", default=None, choices=["f32", "bf16x6"],
+                    help="convolution arithmetic (default: library default = bf16x6, or $ISWM_CONV_MATH)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-fp32-MFMA measurement")
     return ap.parse_args()
 
 
@@ -121,18 +138,29 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # rehearsal knobs (single-GPU box): ISWM_DIST_BACKEND=gloo runs the N > 1 path with every rank on GPU
+    # $ISWM_FORCE_DEVICE; the driver's real runs use RCCL ("nccl") with one GPU per rank
+    backend = os.environ.get("ISWM_DIST_BACKEND", "nccl")
+    if "ISWM_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["ISWM_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from iswm_amd import _lib, ops
     from iswm_amd.network import modeling
     from iswm_amd.optim import FusedSGD
     from iswm_amd.parallel import DistributedDataParallelHIP
     from iswm_amd.utils.loss import CrossEntropyLoss
-    _lib.load()
+    lib = _lib.load()
+    if args.conv_math is not None:
+        lib.iswm_set_conv_math(1 if args.conv_math == "bf16x6" else 0)
+    math_name = "bf16x6" if lib.iswm_get_conv_math() == 1 else "f32"
 
     torch.manual_seed(1)                                   # --random_seed 1, train.py:322
     ctor = {"resnet50": modeling.deeplabv3plus_resnet50, "resnet101": modeling.deeplabv3plus_resnet101}[args.model]
@@ -161,10 +189,21 @@ def main():
         sched.step()
         return loss
 
-    for _ in range(args.warmup):
+    # warm-up; its last step is profiled per conv kernel to find the dominant one, so that the timed region
+    # only brackets THAT kernel's launches with events (bracketing all ~350 conv launches costs ~3 % of a step)
+    kprof, warm_summary = None, None
+    for i in range(args.warmup):
+        if i == args.warmup - 1 and not args.no_kernel_timing:
+            torch.cuda.synchronize()
+            ops.KPROF = ops.KernelProfile()
         step()
-    kprof = None
-    if not args.no_kernel_timing:
+    if ops.KPROF is not None:
+        torch.cuda.synchronize()
+        warm_summary = ops.KPROF.summary()
+        ops.KPROF = None
+        dominant = max(warm_summary.items(), key=lambda kv: kv[1]["ms"])[0]
+        kprof = ops.KernelProfile(only=dominant)
+    elif not args.no_kernel_timing:
         kprof = ops.KernelProfile()
     if world > 1:
         dist.barrier()
@@ -173,6 +212,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enqueued = time.perf_counter() - t0          # host time to enqueue the work (GPU still running)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -187,7 +227,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            "metric": "training images/sec (513x513) DeepLabV3+-ResNet101",
+            "metric": "training images/sec (%dx%d) DeepLabV3+-%s" % (S, S, {"resnet101": "ResNet101", "resnet50": "ResNet50"}[args.model]),
             "value": round(B * world * args.steps / dt, 3),
             "unit": "images/sec",
             "n_gpus": world,
@@ -202,29 +242,54 @@ def main():
             "config": {
                 "workload": "deeplabv3plus_%s output_stride=%d, %dx%d synthetic tiles, %d images/GPU "
                             "(BASELINE.json configs[2]: global batch 128 over 8 GPUs), weighted CE [1,3], "
-                            "SGD-nesterov + cosine LR, fp32 MFMA" % (args.model, args.output_stride, S, S, B),
+                            "SGD-nesterov + cosine LR; fp32 tensors, conv products via %s" %
+                            (args.model, args.output_stride, S, S, B,
+                             "six bf16 MFMAs on an exact 3-way operand split (bf16x6, fp32-level error)"
+                             if math_name == "bf16x6" else "v_mfma_f32_32x32x2_f32"),
+                "conv_math": math_name,
                 "global_batch": B * world,
                 "parallelism": "dp%d" % world,
             },
             "final_loss": round(final_loss, 6),
+            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
         }
         if kprof is not None:
             summ = kprof.summary()
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             name, d = dom
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            is_x6 = "x6" in name or ", true>" in name
+            peak = X6_PEAK_TFLOPS if is_x6 else FP32_MFMA_PEAK_TFLOPS
             out["roofline"] = {
-                "kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "peak_basis": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 MAC (bf16x6)" if is_x6
+                               else "fp32 MFMA dense peak"),
+                "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(name),
                 "launches": d["launches"], "avg_us": round(d["ms"] * 1e3 / d["launches"], 2),
                 "flops_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
-                "by_kernel": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
-                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                  "launches_per_step": v["launches"] // args.steps}
-                              for k, v in sorted(summ.items())},
-                "conv_ms_per_step": round(sum(v["ms"] for v in summ.values()) / args.steps, 3),
             }
+            if warm_summary is not None:
+                out["roofline"]["by_kernel_warmup_step"] = {
+                    k: {"ms_per_step": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                        "launches_per_step": v["launches"]} for k, v in sorted(warm_summary.items())}
+                out["roofline"]["conv_ms_per_step_warmup"] = round(sum(v["ms"] for v in warm_summary.values()), 3)
+        if world == 1 and math_name == "bf16x6" and not args.no_alt:
+            # same step with the exact-fp32 MFMA kernels, for reference (outside the timed region above)
+            lib.iswm_set_conv_math(0)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / 3
+            lib.iswm_set_conv_math(1)
+            out["alt_conv_math_f32"] = {"value": round(B / dt1, 3), "unit": "images/sec",
+                                        "ms_per_step": round(dt1 * 1e3, 3),
+                                        "note": "identical step on v_mfma_f32_32x32x2_f32 kernels (ISWM_CONV_MATH=f32)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.output_stride, S)
         print(json.dumps(out), flush=True)

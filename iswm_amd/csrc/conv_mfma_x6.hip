@@ -140,7 +140,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             uint2 h, m, l;
+#if defined(ISWM_X6_FAKE) && ISWM_X6_FAKE >= 2
+            h = make_uint2(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y)); m = h; l = h;   // timing experiment only
+#else
             split3(ra[j], h, m, l);
+#endif
             unsigned char* p = As + (r0 + 32 * j) * X6_PITCH + q * 8;
             *reinterpret_cast<uint2*>(p) = h;
             *reinterpret_cast<uint2*>(p + PLANE_A) = m;
@@ -149,7 +153,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_x6(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             uint2 h, m, l;
+#if defined(ISWM_X6_FAKE) && ISWM_X6_FAKE >= 1
+            h = make_uint2(__float_as_uint(rb[j].x), __float_as_uint(rb[j].y)); m = h; l = h;   // timing experiment only
+#else
             split3(rb[j], h, m, l);
+#endif
             unsigned char* p = Bs + (r0 + 32 * j) * X6_PITCH + q * 8;
             *reinterpret_cast<uint2*>(p) = h;
             *reinterpret_cast<uint2*>(p + PLANE_B) = m;

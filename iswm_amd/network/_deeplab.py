@@ -151,18 +151,22 @@ class DeepLabHeadV3Plus(_hip.HipModule):
         n, hl, wl, _ = low.shape
         c_low = self.project[0].out_channels
         c_aspp = self.aspp.project[0].out_channels
-        cat = ops.new_act(n, hl, wl, c_low + c_aspp, low.device)
+        c_cat = c_low + c_aspp
+        c_buf = self.classifier[0].cin_p            # 304 -> 320: zero channels keep the K axis a multiple of 32
+        cat = ops.new_act(n, hl, wl, c_buf, low.device)
+        if c_buf > c_cat:
+            cat[..., c_cat:].zero_()
         self.project.fwd(low, save, out=cat[..., :c_low])
         a = self.aspp.fwd(hi, save)
-        ops.bilinear_fwd(a, hl, wl, out=cat[..., c_low:])
-        self._saved = (tuple(a.shape), c_low) if save else None
+        ops.bilinear_fwd(a, hl, wl, out=cat[..., c_low:c_cat])
+        self._saved = (tuple(a.shape), c_low, c_cat) if save else None
         return self.classifier.fwd(cat, save)
 
     def bwd(self, dy, sink):
-        (n, ha, wa, ca), c_low = self._saved
+        (n, ha, wa, ca), c_low, c_cat = self._saved
         self._saved = None
         dcat = self.classifier.bwd(dy, sink)
-        da = ops.bilinear_bwd(dcat[..., c_low:], ha, wa)
+        da = ops.bilinear_bwd(dcat[..., c_low:c_cat], ha, wa)
         dhi = self.aspp.bwd(da, sink)
         dlow = self.project.bwd(dcat[..., :c_low], sink)
         return {'low_level': dlow, 'out': dhi}

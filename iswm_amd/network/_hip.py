@@ -28,6 +28,15 @@ def pad4(c):
     return (c + 3) // 4 * 4
 
 
+def pad_cin(c):
+    """channel count a conv's INPUT buffer is padded to: groups of 4 (16-byte loads) always; wide inputs
+    that are not a multiple of the K chunk (the decoder's 304 = 48 + 256) go up to the next multiple of 32
+    so the tap-uniform / bf16x6 kernels apply -- 5 % more MACs on zero channels buys a 1.5x faster kernel"""
+    if c % 32 == 0 or c < 128:
+        return pad4(c)
+    return (c + 31) // 32 * 32
+
+
 def dense_flat(t):
     """1-D view over the dense memory of a parameter-shaped tensor (contiguous or
     channels_last)."""
@@ -138,7 +147,7 @@ class Conv2d(HipModule, nn.Conv2d):
     # -- operand views -----------------------------------------------------------------
     @property
     def cin_p(self):
-        return pad4(self.in_channels)
+        return pad_cin(self.in_channels)
 
     @property
     def cout_p(self):

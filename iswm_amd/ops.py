@@ -56,18 +56,22 @@ class KernelProfile:
     kernels are launched on (torch's current stream).  bench.py turns it on for the timed region to
     report the MFMA roofline fraction; it is off (None) otherwise and costs nothing."""
 
-    def __init__(self):
-        self.records = []   # (kernel name, start event, end event, algorithmic flops)
+    def __init__(self, only=None):
+        self.records = []   # (kernel name, start event, end event, algorithmic flops, geometry tag)
+        self.only = only    # when set: time launches of this kernel only (keeps the timed region light)
 
     def begin(self):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
+        return True
 
     def end(self, name, start, flops, tag=None):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        self.records.append((name, start, e, flops, tag))
+        # the bracketing events are recorded by _timed(); kept for API symmetry
+        raise NotImplementedError
+
+    def wants(self, name):
+        return self.only is None or name == self.only or name + "+reduce" == self.only
+
+    def add(self, name, a, b, flops, tag):
+        self.records.append((name, a, b, flops, tag))
 
     def summary(self):
         """{name: dict(launches, ms, flops)} -- call after torch.cuda.synchronize()"""
@@ -139,11 +143,42 @@ class ConvGeom:
                         self.stride, self.pad, self.dil, ldx, ldy)
 
 
+_NAME_CACHE = {}
+
+
 def _kernel_name(d, kind):
     """device kernel symbol the library launches for this geometry (labels profile records)"""
-    buf = ctypes.create_string_buffer(64)
-    _lib.load().iswm_conv2d_kernel_name(ctypes.byref(d), kind, buf, 64)
-    return buf.value.decode()
+    lib = _lib.load()
+    key = (kind, lib.iswm_get_conv_math(), d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.pad, d.dil)
+    name = _NAME_CACHE.get(key)
+    if name is None:
+        buf = ctypes.create_string_buffer(64)
+        lib.iswm_conv2d_kernel_name(ctypes.byref(d), kind, buf, 64)
+        name = _NAME_CACHE[key] = buf.value.decode()
+    return name
+
+
+class _timed:
+    """bracket one conv launch with HIP events on the launch stream when a KernelProfile is active"""
+
+    def __init__(self, d, kind, g, suffix=""):
+        self.on = False
+        if KPROF is not None:
+            name = _kernel_name(d, kind) + suffix
+            if KPROF.wants(name):
+                self.on, self.name, self.g = True, name, g
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            KPROF.add(self.name, self.a, b, self.g.flops(), self.g.tag())
+        return False
 
 
 def _check_w(w_ohwi, g):
@@ -166,10 +201,8 @@ def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
         lib = _lib.load()
         tiles = (lib.iswm_conv2d_stat_tiles(ctypes.byref(d)), lib.iswm_conv2d_stat_tile_rows(ctypes.byref(d)))
         partials = torch.empty((2, tiles[0], g.cout), dtype=torch.float32, device=x.device)
-    t0 = KPROF.begin() if KPROF is not None else None
-    call("iswm_conv2d_fwd", ctypes.byref(d), _p(x), _p(w_ohwi), _p(bias), _p(out), _p(partials), _stream())
-    if t0 is not None:
-        KPROF.end(_kernel_name(d, 0), t0, g.flops(), g.tag())
+    with _timed(d, 0, g):
+        call("iswm_conv2d_fwd", ctypes.byref(d), _p(x), _p(w_ohwi), _p(bias), _p(out), _p(partials), _stream())
     return out, partials, tiles
 
 
@@ -186,15 +219,11 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
         # bf16x6 math: the matrix cores want the K axis (tap, cout) contiguous -> transposed weights
         wt = torch.empty((g.cin, g.kh, g.kw, g.cout), dtype=torch.float32, device=dy.device)
         call("iswm_transpose_weights", ctypes.byref(d), _p(w_ohwi), _p(wt), _stream())
-        t0 = KPROF.begin() if KPROF is not None else None
-        call("iswm_conv2d_dgrad_wt", ctypes.byref(d), _p(dy), _p(wt), _p(dx), int(bool(accumulate)), _stream())
-        if t0 is not None:
-            KPROF.end(_kernel_name(d, 1), t0, g.flops(), g.tag())
+        with _timed(d, 1, g):
+            call("iswm_conv2d_dgrad_wt", ctypes.byref(d), _p(dy), _p(wt), _p(dx), int(bool(accumulate)), _stream())
         return dx
-    t0 = KPROF.begin() if KPROF is not None else None
-    call("iswm_conv2d_dgrad", ctypes.byref(d), _p(dy), _p(w_ohwi), _p(dx), int(bool(accumulate)), _stream())
-    if t0 is not None:
-        KPROF.end(_kernel_name(d, 1), t0, g.flops(), g.tag())
+    with _timed(d, 1, g):
+        call("iswm_conv2d_dgrad", ctypes.byref(d), _p(dy), _p(w_ohwi), _p(dx), int(bool(accumulate)), _stream())
     return dx
 
 
@@ -207,10 +236,8 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
     d = g.desc(ldx, ldy)
     need = _lib.load().iswm_conv2d_wgrad_workspace(ctypes.byref(d))
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device) if need else None
-    t0 = KPROF.begin() if KPROF is not None else None
-    call("iswm_conv2d_wgrad", ctypes.byref(d), _p(x), _p(dy), _p(dw_ohwi), _p(ws), need, _stream())
-    if t0 is not None:
-        KPROF.end(_kernel_name(d, 2) + "+reduce", t0, g.flops(), g.tag())
+    with _timed(d, 2, g, "+reduce"):
+        call("iswm_conv2d_wgrad", ctypes.byref(d), _p(x), _p(dy), _p(dw_ohwi), _p(ws), need, _stream())
     return dw_ohwi
 
 
