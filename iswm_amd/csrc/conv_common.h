@@ -68,6 +68,7 @@ void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, 
 // tap-uniform fast path (conv_mfma_u.hip); each returns false when the geometry does not qualify
 bool launch_conv_fwd_u(ConvArgs a, hipStream_t s);
 void conv_pick_tile(int64_t M, int cols, int* bm, int* bn);
+void conv_pick_tile_x6(int64_t M, int cols, int K, bool dgrad, bool pointwise, int* bm, int* bn);
 int conv_fwd_tile_rows(int64_t M, int Cin, int Cout);   // rows per forward M tile == rows per BN partial
 bool launch_conv_dgrad_u(ConvArgs a, hipStream_t s);
 

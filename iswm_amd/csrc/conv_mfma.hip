@@ -361,7 +361,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
     constexpr int MB = BM / 64, NB = BN / 64;
     constexpr int AQ = BM / 4, AKR = 256 / AQ, APASS = 32 / AKR;
     constexpr int BQ = BN / 4, BKR = 256 / BQ, BPASS = 32 / BKR;
-    constexpr int XPA = BM * 2 + 64, XPB = BN * 2 + 64;              // X6 row pitches (bytes)
+    // X6 row pitches (bytes).  128-column planes are packed (256 B rows, 48 KB per workgroup -> 3 per CU) and
+    // the column offset is XORed with 64*(k&3), which lands the 4 k-rows of one transposing read on disjoint
+    // bank quarters exactly as the +64 B padding does for the 64-column planes.
+    constexpr int XPA = BM == 128 ? 256 : BM * 2 + 64, XPB = BN == 128 ? 256 : BN * 2 + 64;
+    constexpr int SWA = BM == 128 ? 64 : 0, SWB = BN == 128 ? 64 : 0;   // swizzle step (bytes)
     constexpr int XPLA = 32 * XPA, XPLB = 32 * XPB;                  // X6 plane sizes (bytes)
     constexpr int SMEM_BYTES = X6 ? 3 * (XPLA + XPLB) : 2 * 32 * (BM + BN) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
@@ -487,7 +491,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
             for (int j = 0; j < APASS; ++j) {
                 uint2 h, m, l;
                 split3(ra[j], h, m, l);
-                unsigned char* p = Ax + (ak0 + AKR * j) * XPA + aq * 8;
+                const int kr = ak0 + AKR * j;
+                unsigned char* p = Ax + kr * XPA + ((aq * 8) ^ ((kr & 3) * SWA));
                 *reinterpret_cast<uint2*>(p) = h;
                 *reinterpret_cast<uint2*>(p + XPLA) = m;
                 *reinterpret_cast<uint2*>(p + 2 * XPLA) = l;
@@ -496,7 +501,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
             for (int j = 0; j < BPASS; ++j) {
                 uint2 h, m, l;
                 split3(rb[j], h, m, l);
-                unsigned char* p = Bx + (bk0 + BKR * j) * XPB + bq * 8;
+                const int kr = bk0 + BKR * j;
+                unsigned char* p = Bx + kr * XPB + ((bq * 8) ^ ((kr & 3) * SWB));
                 *reinterpret_cast<uint2*>(p) = h;
                 *reinterpret_cast<uint2*>(p + XPLB) = m;
                 *reinterpret_cast<uint2*>(p + 2 * XPLB) = l;
@@ -540,8 +546,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
         const int th = tg >> 1, tc = (tg & 1) * 16 + tp * 4;
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-        auto tr_frag = [&](const unsigned char* plane, int pitch, int col0, int ks) -> uint4 {
-            const unsigned char* p = plane + (ks * 16 + th * 8 + tq) * pitch + (col0 + tc) * 2;
+        auto tr_frag = [&](const unsigned char* plane, int pitch, int sw, int col0, int ks) -> uint4 {
+            const unsigned char* p = plane + (ks * 16 + th * 8 + tq) * pitch + (((col0 + tc) * 2) ^ (tq * sw));
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
             s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * pitch));
             uint2 a2 = __builtin_bit_cast(uint2, lo), b2 = __builtin_bit_cast(uint2, hi);
@@ -560,16 +566,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     const int c0 = wm * (BM / 2) + mb * 32;
-                    ah[mb] = tr_frag(Ax, XPA, c0, ks);
-                    am[mb] = tr_frag(Ax + XPLA, XPA, c0, ks);
-                    al[mb] = tr_frag(Ax + 2 * XPLA, XPA, c0, ks);
+                    ah[mb] = tr_frag(Ax, XPA, SWA, c0, ks);
+                    am[mb] = tr_frag(Ax + XPLA, XPA, SWA, c0, ks);
+                    al[mb] = tr_frag(Ax + 2 * XPLA, XPA, SWA, c0, ks);
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int c0 = wn * (BN / 2) + nb * 32;
-                    bh[nb] = tr_frag(Bx, XPB, c0, ks);
-                    bm[nb] = tr_frag(Bx + XPLB, XPB, c0, ks);
-                    bl[nb] = tr_frag(Bx + 2 * XPLB, XPB, c0, ks);
+                    bh[nb] = tr_frag(Bx, XPB, SWB, c0, ks);
+                    bm[nb] = tr_frag(Bx + XPLB, XPB, SWB, c0, ks);
+                    bl[nb] = tr_frag(Bx + 2 * XPLB, XPB, SWB, c0, ks);
                 }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
@@ -700,7 +706,7 @@ struct WgradPlan {
     int bm, bn, MT, NT, nsplit, psplit;
 };
 
-static WgradPlan plan_wgrad(const iswm_conv_desc* d) {
+static WgradPlan plan_wgrad(const iswm_conv_desc* d, bool x6) {
     WgradPlan p;
     const int Ktot = d->KH * d->KW * d->Cin;
     p.bm = (d->Cout % 128 == 0) ? 128 : 64;
@@ -713,6 +719,9 @@ static WgradPlan plan_wgrad(const iswm_conv_desc* d) {
     // Split count: minimise  rounds x (chunks per workgroup) x chunk time  +  slab write/read time, where a
     // round is 512 co-resident workgroups (2 per CU) and a 128x128x32 chunk takes ~4.5 us when two
     // workgroups share a CU.  tiles*splits just above a multiple of 512 costs a whole extra round.
+    // (Three bf16x6 workgroups per CU fit in LDS and registers but measured no faster than two: r01 notes.)
+    (void)x6;
+    const int64_t slots = 512;
     const double chunk_us = 4.5 * (double)(p.bm * p.bn) / 16384.0;
     const double slab_us = (double)d->Cout * Ktot * 8.0 / 4.0e6;   // one slab written + read at ~4 TB/s
     int64_t maxs = (P + 255) / 256;                                 // at least 256 pixels per split
@@ -723,7 +732,7 @@ static WgradPlan plan_wgrad(const iswm_conv_desc* d) {
     for (int64_t ns = 1; ns <= maxs; ++ns) {
         int64_t ps = ((P + ns - 1) / ns + 31) / 32 * 32;
         int64_t nsp = (P + ps - 1) / ps;
-        int64_t rounds = (tiles * nsp + 511) / 512;
+        int64_t rounds = (tiles * nsp + slots - 1) / slots;
         double t = (double)rounds * (double)(ps / 32 + 3) * chunk_us + (nsp > 1 ? (double)nsp * slab_us + 5.0 : 0.0);
         if (t < best) {
             best = t;
@@ -760,7 +769,8 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
     if (kind == 0) {
         const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
         if (d->Cin % 32 == 0) {
-            conv_pick_tile(M, d->Cout, &bm, &bn);
+            if (conv_math() == 1) conv_pick_tile_x6(M, d->Cout, d->KH * d->KW * d->Cin, false, d->KH * d->KW == 1, &bm, &bn);
+            else conv_pick_tile(M, d->Cout, &bm, &bn);
             snprintf(buf, buflen, conv_math() == 1 ? "k_conv_x6<%d, %d, false>" : "k_conv_fwd_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_fwd<%d>", use_narrow_tile((M + 127) / 128, d->Cout) ? 64 : 128);
@@ -768,14 +778,15 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
     } else if (kind == 1) {
         const int64_t M = (int64_t)d->N * d->H * d->W;
         if (d->Cout % 32 == 0) {
-            conv_pick_tile(M, d->Cin, &bm, &bn);
+            if (conv_math() == 1) conv_pick_tile_x6(M, d->Cin, d->KH * d->KW * d->Cout, true, d->KH * d->KW == 1, &bm, &bn);
+            else conv_pick_tile(M, d->Cin, &bm, &bn);
             if (conv_math() == 1) snprintf(buf, buflen, "k_conv_x6<%d, %d, true>", bm, bn);
             else snprintf(buf, buflen, "k_conv_dgrad_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_dgrad<%d>", use_narrow_tile((M + 127) / 128, d->Cin) ? 64 : 128);
         }
     } else {
-        WgradPlan p = plan_wgrad(d);
+        WgradPlan p = plan_wgrad(d, conv_math() == 1);
         const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
         const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
         snprintf(buf, buflen, "k_conv_wgrad<%d, %d, %d, %s>", p.bm, p.bn, mode, conv_math() == 1 ? "true" : "false");
@@ -785,6 +796,11 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
 
 extern "C" int iswm_conv2d_stat_tile_rows(const iswm_conv_desc* d) {
     if (!d) return 0;
+    if (conv_math() == 1 && d->Cin % 32 == 0) {
+        int bm, bn;
+        conv_pick_tile_x6((int64_t)d->N * d->Ho * d->Wo, d->Cout, d->KH * d->KW * d->Cin, false, d->KH * d->KW == 1, &bm, &bn);
+        return bm;
+    }
     return conv_fwd_tile_rows((int64_t)d->N * d->Ho * d->Wo, d->Cin, d->Cout);
 }
 
@@ -807,7 +823,7 @@ extern "C" int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const fl
     hipStream_t s = (hipStream_t)stream;
     if (conv_math() == 1 && d->Cin % 32 == 0) {
         int bm, bn;
-        conv_pick_tile(a.M, d->Cout, &bm, &bn);
+        conv_pick_tile_x6(a.M, d->Cout, a.Ktot, false, d->KH * d->KW == 1, &bm, &bn);
         if (launch_conv_fwd_x6(a, s, bm, bn)) return check_launch("conv_fwd_x6");
     }
     if (launch_conv_fwd_u(a, s)) return check_launch("conv_fwd_u");
@@ -870,14 +886,14 @@ extern "C" int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, co
     a.M = d->N * d->H * d->W;
     a.Ktot = d->KH * d->KW * d->Cout;
     int bm, bn;
-    conv_pick_tile(a.M, d->Cin, &bm, &bn);
+    conv_pick_tile_x6(a.M, d->Cin, a.Ktot, true, d->KH * d->KW == 1, &bm, &bn);
     launch_conv_dgrad_x6(a, (hipStream_t)stream, bm, bn);
     return check_launch("conv_dgrad_x6");
 }
 
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
-    WgradPlan p = plan_wgrad(d);
+    WgradPlan p = plan_wgrad(d, conv_math() == 1);
     if (p.nsplit <= 1) return 0;
     return (size_t)p.nsplit * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
 }
@@ -887,7 +903,7 @@ extern "C" int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const 
     if (int e = validate(d)) return e;
     ISWM_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
     ISWM_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw), "conv_wgrad: pointers must be 16-byte aligned");
-    WgradPlan p = plan_wgrad(d);
+    WgradPlan p = plan_wgrad(d, conv_math() == 1);
     const size_t need = iswm_conv2d_wgrad_workspace(d);
     ISWM_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))),
                  "conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);

@@ -13,6 +13,8 @@
 //     most of the tile-quantisation loss on the 33x33 stages (137 row tiles x 2 column tiles = 274
 //     workgroups of 128x128 for 512 slots).
 // MFMA scheme, LDS layouts and epilogues are those of conv_mfma.hip.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace iswm {
@@ -399,6 +401,14 @@ struct TilePick {
 };
 
 static TilePick pick_tile(int64_t M, int cols) {
+    if (const char* e = getenv("ISWM_TILE")) {          // tuning override: "128x128" | "128x64" | "64x64"
+        int bm = 0, bn = 0;
+        if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) &&
+            !(bm == 64 && bn == 128)) {
+            if (bn == 128 && (cols <= 64 || (cols % 128 != 0 && cols % 128 <= 64))) bn = 64;
+            return TilePick{bm, bn};
+        }
+    }
     struct Cand {
         int bm, bn;
         double eff;
