@@ -57,7 +57,8 @@ typedef struct {
  * 304-channel decoder input) always run on the fp32 MFMA kernels. */
 int iswm_set_conv_math(int mode);
 int iswm_get_conv_math(void);
-/* name of the device kernel a call with this geometry launches (kind 0 fwd, 1 dgrad, 2 wgrad) --
+/* name of the device kernel a call with this geometry launches (kind 0 fwd, 1 dgrad, 2 wgrad, 3 fwd_packed,
+ * 4 dgrad_packed) --
  * lets a profiler label its timings with the symbol rocprofv3 reports */
 int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen);
 /* M tiling the forward kernel will use for this geometry: rows per tile (128 or 64) and number of
@@ -80,6 +81,17 @@ int iswm_transpose_weights(const iswm_conv_desc* d, const float* w, float* wt, i
 int iswm_conv2d_dgrad_wants_wt(const iswm_conv_desc* d);
 int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, const float* wt, float* dx, int accumulate,
                          iswm_stream_t stream);
+/* bf16x6 with pre-split weights: iswm_conv2d_pack_weights splits a weight tensor into its three bf16 planes and
+ * stores them in MFMA fragment order (kind 0: for the forward conv, 1: for the data gradient, which also transposes);
+ * the *_packed kernels then load the weight operand straight into registers.  iswm_conv2d_packed_weight_bytes
+ * returns the buffer size, or 0 when the packed path does not apply (conv math f32, or the gathered channel
+ * count -- Cin forward, Cout data gradient -- is not a multiple of 32). */
+size_t iswm_conv2d_packed_weight_bytes(const iswm_conv_desc* d, int kind);
+int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed, iswm_stream_t stream);
+int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, const void* wpk, const float* bias,
+                           float* y, float* stat_partials, iswm_stream_t stream);
+int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy, const void* wpk, float* dx, int accumulate,
+                             iswm_stream_t stream);
 /* dw[Cout][KH][KW][Cin] = sum over pixels.  workspace holds split-K slabs. */
 size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d);
 int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -33,6 +33,10 @@ _SIGS = {
     "iswm_transpose_weights": (c_int, [POINTER(ConvDesc), P, P, P]),
     "iswm_conv2d_dgrad_wants_wt": (c_int, [POINTER(ConvDesc)]),
     "iswm_conv2d_dgrad_wt": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
+    "iswm_conv2d_packed_weight_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "iswm_conv2d_pack_weights": (c_int, [POINTER(ConvDesc), c_int, P, P, P]),
+    "iswm_conv2d_fwd_packed": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
+    "iswm_conv2d_dgrad_packed": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
     "iswm_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "iswm_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
     "iswm_colstat_tiles": (c_int, [c_int64]),

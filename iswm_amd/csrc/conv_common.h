@@ -63,6 +63,9 @@ __device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, ui
 // bf16x6 path (conv_mfma_x6.hip): fp32-accurate products from six bf16 MFMAs
 bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn);
 bool launch_conv_dgrad_x6(ConvArgs a, hipStream_t s, int bm, int bn);
+bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm);
+size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad);
+void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, hipStream_t s);
 void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s);
 
 // tap-uniform fast path (conv_mfma_u.hip); each returns false when the geometry does not qualify

@@ -764,14 +764,22 @@ extern "C" int iswm_set_conv_math(int mode) {
 extern "C" int iswm_get_conv_math(void) { return conv_math(); }
 
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
-    ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 2, "kernel_name: bad argument");
+    ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 4, "kernel_name: bad argument");
+    if (kind >= 3) {   // 3 / 4: iswm_conv2d_fwd_packed / iswm_conv2d_dgrad_packed
+        const bool dg = kind == 4;
+        int pbm, pbn;
+        conv_pick_tile_x6(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, dg ? d->Cin : d->Cout,
+                          d->KH * d->KW * (dg ? d->Cout : d->Cin), dg, d->KH * d->KW == 1, &pbm, &pbn);
+        snprintf(buf, buflen, "k_conv_x6<%d, 64, %s, true>", pbm, dg ? "true" : "false");
+        return 0;
+    }
     int bm, bn;
     if (kind == 0) {
         const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
         if (d->Cin % 32 == 0) {
             if (conv_math() == 1) conv_pick_tile_x6(M, d->Cout, d->KH * d->KW * d->Cin, false, d->KH * d->KW == 1, &bm, &bn);
             else conv_pick_tile(M, d->Cout, &bm, &bn);
-            snprintf(buf, buflen, conv_math() == 1 ? "k_conv_x6<%d, %d, false>" : "k_conv_fwd_u<%d, %d>", bm, bn);
+            snprintf(buf, buflen, conv_math() == 1 ? "k_conv_x6<%d, %d, false, false>" : "k_conv_fwd_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_fwd<%d>", use_narrow_tile((M + 127) / 128, d->Cout) ? 64 : 128);
         }
@@ -780,7 +788,7 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         if (d->Cout % 32 == 0) {
             if (conv_math() == 1) conv_pick_tile_x6(M, d->Cin, d->KH * d->KW * d->Cout, true, d->KH * d->KW == 1, &bm, &bn);
             else conv_pick_tile(M, d->Cin, &bm, &bn);
-            if (conv_math() == 1) snprintf(buf, buflen, "k_conv_x6<%d, %d, true>", bm, bn);
+            if (conv_math() == 1) snprintf(buf, buflen, "k_conv_x6<%d, %d, true, false>", bm, bn);
             else snprintf(buf, buflen, "k_conv_dgrad_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_dgrad<%d>", use_narrow_tile((M + 127) / 128, d->Cin) ? 64 : 128);
@@ -889,6 +897,57 @@ extern "C" int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, co
     conv_pick_tile_x6(a.M, d->Cin, a.Ktot, true, d->KH * d->KW == 1, &bm, &bn);
     launch_conv_dgrad_x6(a, (hipStream_t)stream, bm, bn);
     return check_launch("conv_dgrad_x6");
+}
+
+/* ---- bf16x6 with pre-split, fragment-ordered weights ("packed"): kind 0 = forward, 1 = data gradient ---- */
+extern "C" size_t iswm_conv2d_packed_weight_bytes(const iswm_conv_desc* d, int kind) {
+    if (!d || conv_math() != 1 || (kind != 0 && kind != 1)) return 0;
+    const int gc = kind ? d->Cout : d->Cin;
+    if (gc % 32 != 0) return 0;
+    return packed_weight_bytes_x6(d->Cout, d->KH * d->KW, d->Cin, kind == 1);
+}
+
+extern "C" int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed,
+                                        iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(kind == 0 || kind == 1, "pack_weights: kind must be 0 (forward) or 1 (data gradient)");
+    ISWM_REQUIRE(w && packed && aligned16(packed), "pack_weights: bad pointer");
+    ISWM_REQUIRE((kind ? d->Cout : d->Cin) % 32 == 0, "pack_weights: gathered channel count must be a multiple of 32");
+    launch_pack_weights_x6(w, packed, d->Cout, d->KH * d->KW, d->Cin, kind == 1, (hipStream_t)stream);
+    return check_launch("pack_weights");
+}
+
+extern "C" int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, const void* wpk, const float* bias,
+                                      float* y, float* stat_partials, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(x && wpk && y, "conv_fwd_packed: null pointer");
+    ISWM_REQUIRE(aligned16(x) && aligned16(wpk) && aligned16(y), "conv_fwd_packed: pointers must be 16-byte aligned");
+    ISWM_REQUIRE(d->Cin % 32 == 0, "conv_fwd_packed: Cin must be a multiple of 32");
+    ConvArgs a = base_args(d);
+    a.x = x; a.w = reinterpret_cast<const float*>(wpk); a.bias = bias; a.y = y; a.stats = stat_partials;
+    a.M = d->N * d->Ho * d->Wo;
+    a.Ktot = d->KH * d->KW * d->Cin;
+    int bm, bn;
+    conv_pick_tile_x6(a.M, d->Cout, a.Ktot, false, d->KH * d->KW == 1, &bm, &bn);
+    launch_conv_x6_pk(a, (hipStream_t)stream, false, bm);
+    return check_launch("conv_fwd_packed");
+}
+
+extern "C" int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy, const void* wpk, float* dx,
+                                        int accumulate, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(dy && wpk && dx, "conv_dgrad_packed: null pointer");
+    ISWM_REQUIRE(aligned16(dy) && aligned16(wpk) && aligned16(dx), "conv_dgrad_packed: pointers must be 16-byte aligned");
+    ISWM_REQUIRE(d->Cout % 32 == 0, "conv_dgrad_packed: Cout must be a multiple of 32");
+    ConvArgs a = base_args(d);
+    a.x = dy; a.w = reinterpret_cast<const float*>(wpk); a.y = dx; a.accumulate = accumulate;
+    a.ldx = d->ldy; a.ldy = d->ldx;
+    a.M = d->N * d->H * d->W;
+    a.Ktot = d->KH * d->KW * d->Cout;
+    int bm, bn;
+    conv_pick_tile_x6(a.M, d->Cin, a.Ktot, true, d->KH * d->KW == 1, &bm, &bn);
+    launch_conv_x6_pk(a, (hipStream_t)stream, true, bm);
+    return check_launch("conv_dgrad_packed");
 }
 
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {

@@ -28,13 +28,16 @@ constexpr int X6_PITCH = 80;   // bytes per LDS row of one bf16 plane (32 k x 2 
 // DGRAD == true : data gradient.  rows = INPUT pixels, A = dy gathered per tap (a.x = dy, pitch a.ldx),
 //                 B = TRANSPOSED weights [cin][(tap, cout)] (iswm_transpose_weights), output a.y = dx.
 // In both cases the GEMM K axis (tap, gathered channel) is contiguous in memory for A and B.
-template <int BM, int BN, bool DGRAD>
+// BD == true ("B direct"): the weight operand was split and laid out in MFMA fragment order ahead of time
+//   (k_pack_weights_x6: [col block of 32][k block of 16][plane][lane] x 16 B), so each wave loads its B fragments
+//   straight from global/L2 into registers -- no split arithmetic, LDS write or LDS read for B.  a.w = packed.
+template <int BM, int BN, bool DGRAD, bool BD>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 : 4)) void k_conv_x6(const ConvArgs a) {
     const int GC = DGRAD ? a.Cout : a.Cin;     // channels of the gathered operand (per tap)
     const int NC = DGRAD ? a.Cin : a.Cout;     // output columns
     constexpr int MB = BM / 64, NB = BN / 64, AR = BM / 32, BR = BN / 32;
     constexpr int PLANE_A = BM * X6_PITCH, PLANE_B = BN * X6_PITCH;          // bytes
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (PLANE_A + PLANE_B)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (PLANE_A + (BD ? 0 : PLANE_B))];
     unsigned char* As = smem;                 // [3][BM][80 B]
     unsigned char* Bs = smem + 3 * PLANE_A;   // [3][BN][80 B]
 
@@ -84,6 +87,9 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
     }
     const int taps = a.KH * a.KW;
     const int nCC = GC >> 5;
+    // BD: this wave's packed fragments: column block (n0 + wn*BN/2)/32 + nb, 192 uint4 per (column block, k16)
+    const uint4* wpk = reinterpret_cast<const uint4*>(a.w) + (size_t)((n0 + wn * (BN / 2)) >> 5) * (a.Ktot >> 4) * 192 + lane;
+    const size_t wpk_nb = (size_t)(a.Ktot >> 4) * 192;
 
     const float* aptr[AR];
     int astep[AR];
@@ -117,10 +123,12 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
             astep[j] = ok ? 32 : 0;
             any |= ok;
         }
+        if constexpr (!BD) {
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            bptr[j] = wok[j] ? wbase[j] + (size_t)tap * GC : g_zero_row_x + q * 4;
-            bstep[j] = wok[j] ? 32 : 0;
+            for (int j = 0; j < BR; ++j) {
+                bptr[j] = wok[j] ? wbase[j] + (size_t)tap * GC : g_zero_row_x + q * 4;
+                bstep[j] = wok[j] ? 32 : 0;
+            }
         }
         return __syncthreads_or(any) != 0;
     };
@@ -141,11 +149,23 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
             ra[j] = ldg4(aptr[j]);
             aptr[j] += astep[j];
         }
+        if constexpr (!BD) {
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            rb[j] = ldg4(bptr[j]);
-            bptr[j] += bstep[j];
+            for (int j = 0; j < BR; ++j) {
+                rb[j] = ldg4(bptr[j]);
+                bptr[j] += bstep[j];
+            }
         }
+    };
+    uint4 bfr[2][NB][3];   // BD: [k half][column block][plane]
+    auto bload = [&]() {   // fragments of the CURRENT chunk (tap, cc)
+        const uint4* p = wpk + (size_t)((tap * nCC + cc) * 2) * 192;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bfr[ks][nb][pl] = p[nb * wpk_nb + (ks * 3 + pl) * 64];
     };
     auto lstore = [&]() {   // split into bf16 planes and write 8 B per plane per row
 #pragma unroll
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
             *reinterpret_cast<uint2*>(p + PLANE_A) = m;
             *reinterpret_cast<uint2*>(p + 2 * PLANE_A) = l;
         }
+        if constexpr (!BD)
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             uint2 h, m, l;
@@ -187,6 +208,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
     bool more = next();
     if (more) gload();
     while (more) {
+        if constexpr (BD) bload();
         lstore();
         __syncthreads();
         const bool more2 = next();
@@ -206,10 +228,16 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const unsigned char* p = Bb + nb * 32 * X6_PITCH + ks * 32;
-                bh[nb] = *reinterpret_cast<const uint4*>(p);
-                bm[nb] = *reinterpret_cast<const uint4*>(p + PLANE_B);
-                bl[nb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_B);
+                if constexpr (BD) {
+                    bh[nb] = bfr[ks][nb][0];
+                    bm[nb] = bfr[ks][nb][1];
+                    bl[nb] = bfr[ks][nb][2];
+                } else {
+                    const unsigned char* p = Bb + nb * 32 * X6_PITCH + ks * 32;
+                    bh[nb] = *reinterpret_cast<const uint4*>(p);
+                    bm[nb] = *reinterpret_cast<const uint4*>(p + PLANE_B);
+                    bl[nb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_B);
+                }
             }
 #if defined(ISWM_X6_V3)
 #define X6_PROD(A_, B_)                                                          \
@@ -293,292 +321,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Warp-specialised 128x128 variant: 8 waves per workgroup, ONE workgroup per CU.
-//   waves 0-3 ("consumers")  : fragment reads + the 48 bf16 MFMAs of a K chunk, 64x64 outputs each
-//   waves 4-7 ("producers")  : global gather -> exact 3-way split (VALU) -> LDS planes of the NEXT chunk
-// The hardware places waves w and w+4 of a workgroup on the same SIMD, so every SIMD hosts exactly one MFMA
-// stream and one VALU/LDS-write stream -- the two pipes overlap by construction instead of relying on two
-// co-resident workgroups drifting out of phase (PMC on the symmetric kernel: MFMA busy 48 %, VALU issue 34 %,
-// almost additive).  LDS is double buffered (2 x 61 KB); one barrier per chunk; producers keep the chunk after
-// next in registers, so global latency hides behind a whole chunk of MFMAs.
-// ------------------------------------------------------------------------------------------
-template <bool DGRAD>
-__global__ __launch_bounds__(512, 2) void k_conv_x6ws(const ConvArgs a) {
-    constexpr int BM = 128, BN = 128, MB = 2, NB = 2, AR = 4, BR = 4;
-    const int GC = DGRAD ? a.Cout : a.Cin;
-    const int NC = DGRAD ? a.Cin : a.Cout;
-    constexpr int PLANE_A = BM * X6_PITCH, PLANE_B = BN * X6_PITCH;
-    constexpr int BUF = 3 * (PLANE_A + PLANE_B);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool producer = wave >= 4;
-    const int cw = wave & 3;                       // consumer wave id (2x2 over the tile)
-    const int wm = cw >> 1, wn = cw & 1, li = lane & 31, lh = lane >> 5;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = L / a.NT, nt = L - mt * a.NT;
-    const int m0 = mt * BM, n0 = nt * BN;
-    // producer thread -> (row slot, 16-byte column): adjacent 8-lane groups take rows r and r+4, whose 64-byte
-    // plane rows (pitch 80 B) fall on disjoint halves of the 128-byte ds_write bank window
-    const int pt = t & 255;
-    const int q = pt & 7, idx = pt >> 3;
-    const int r0 = (idx & ~7) | ((idx & 1) << 2) | ((idx >> 1) & 3);
-
-    const int RH = DGRAD ? a.H : a.Ho, RW = DGRAD ? a.W : a.Wo;
-    const int GH = DGRAD ? a.Ho : a.H, GW = DGRAD ? a.Wo : a.W;
-    const int RHW = RH * RW;
-    int ihb[AR], iwb[AR], pb[AR];
-    const float* wbase[BR];
-    bool wok[BR];
-#pragma unroll
-    for (int j = 0; j < AR; ++j) {
-        int m = m0 + r0 + 32 * j;
-        if (producer && m < a.M) {
-            int n = m / RHW, rem = m - n * RHW;
-            int rh = rem / RW, rw = rem - rh * RW;
-            ihb[j] = DGRAD ? rh + a.pad : rh * a.stride - a.pad;
-            iwb[j] = DGRAD ? rw + a.pad : rw * a.stride - a.pad;
-            pb[j] = n * GH * GW;
-        } else {
-            ihb[j] = -(1 << 28);
-            iwb[j] = 0;
-            pb[j] = 0;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        int n = n0 + r0 + 32 * j;
-        wok[j] = producer && n < NC;
-        wbase[j] = a.w + (size_t)(wok[j] ? n : 0) * a.Ktot + q * 4;
-    }
-    const int taps = a.KH * a.KW;
-    const int nCC = GC >> 5;
-
-    const float* aptr[AR];
-    int astep[AR];
-    const float* bptr[BR];
-    int bstep[BR];
-    auto setup_tap = [&](int tap) -> bool {      // executed by all 512 threads (block-wide vote)
-        const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        const int dh = kh * a.dil, dw = kw * a.dil;
-        int any = 0;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            int gh, gw;
-            bool ok;
-            if (DGRAD) {
-                int th = ihb[j] - dh, tw = iwb[j] - dw;
-                gh = th;
-                gw = tw;
-                ok = th >= 0 && tw >= 0;
-                if (a.stride != 1) {
-                    gh = th / a.stride;
-                    gw = tw / a.stride;
-                    ok = ok && (gh * a.stride == th) && (gw * a.stride == tw);
-                }
-                ok = ok && gh < GH && gw < GW;
-            } else {
-                gh = ihb[j] + dh;
-                gw = iwb[j] + dw;
-                ok = (unsigned)gh < (unsigned)GH && (unsigned)gw < (unsigned)GW;
-            }
-            aptr[j] = ok ? a.x + (size_t)(pb[j] + gh * GW + gw) * a.ldx + q * 4 : g_zero_row_x + q * 4;
-            astep[j] = ok ? 32 : 0;
-            any |= ok;
-        }
-#pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            bptr[j] = wok[j] ? wbase[j] + (size_t)tap * GC : g_zero_row_x + q * 4;
-            bstep[j] = wok[j] ? 32 : 0;
-        }
-        return __syncthreads_or(any) != 0;
-    };
-    int tap = -1, cc = nCC - 1;
-    auto next = [&]() -> bool {
-        if (++cc < nCC) return true;
-        cc = 0;
-        do {
-            if (++tap >= taps) return false;
-        } while (!setup_tap(tap));
-        return true;
-    };
-
-    float4 ra[AR], rb[BR];
-    auto gload = [&]() {
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            ra[j] = ldg4(aptr[j]);
-            aptr[j] += astep[j];
-        }
-#pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            rb[j] = ldg4(bptr[j]);
-            bptr[j] += bstep[j];
-        }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* As = smem + buf * BUF;
-        unsigned char* Bs = As + 3 * PLANE_A;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            uint2 h, m, l;
-            split3(ra[j], h, m, l);
-            unsigned char* p = As + (r0 + 32 * j) * X6_PITCH + q * 8;
-            *reinterpret_cast<uint2*>(p) = h;
-            *reinterpret_cast<uint2*>(p + PLANE_A) = m;
-            *reinterpret_cast<uint2*>(p + 2 * PLANE_A) = l;
-        }
-#pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            uint2 h, m, l;
-            split3(rb[j], h, m, l);
-            unsigned char* p = Bs + (r0 + 32 * j) * X6_PITCH + q * 8;
-            *reinterpret_cast<uint2*>(p) = h;
-            *reinterpret_cast<uint2*>(p + PLANE_B) = m;
-            *reinterpret_cast<uint2*>(p + 2 * PLANE_B) = l;
-        }
-    };
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // pipeline: LDS buffer `cur` holds chunk c, producer registers hold chunk c+1, the iterator is at chunk c+2
-    bool have_c = next();                       // chunk 0 exists?
-    if (producer && have_c) gload();            // regs <- chunk 0
-    bool have_n = have_c ? next() : false;      // chunk 1 exists?
-    if (producer && have_c) {
-        lstore(0);                              // LDS[0] <- chunk 0
-        if (have_n) gload();                    // regs <- chunk 1
-    }
-    __syncthreads();
-    int cur = 0;
-    while (have_c) {
-        const bool have_nn = have_n ? next() : false;   // chunk c+2 exists?  (may contain a block-wide vote)
-        if (producer) {
-            if (have_n) {
-                lstore(cur ^ 1);                // LDS[cur^1] <- chunk c+1 (consumers finished reading it a barrier ago)
-                if (have_nn) gload();           // regs <- chunk c+2
-            }
-        } else {
-            const unsigned char* As = smem + cur * BUF;
-            const unsigned char* Bs = As + 3 * PLANE_A;
-            const unsigned char* Ab = As + (wm * 64 + li) * X6_PITCH + lh * 16;
-            const unsigned char* Bb = Bs + (wn * 64 + li) * X6_PITCH + lh * 16;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint4 ah[MB], am[MB], al[MB], bh[NB], bm[NB], bl[NB];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const unsigned char* p = Ab + mb * 32 * X6_PITCH + ks * 32;
-                    ah[mb] = *reinterpret_cast<const uint4*>(p);
-                    am[mb] = *reinterpret_cast<const uint4*>(p + PLANE_A);
-                    al[mb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_A);
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const unsigned char* p = Bb + nb * 32 * X6_PITCH + ks * 32;
-                    bh[nb] = *reinterpret_cast<const uint4*>(p);
-                    bm[nb] = *reinterpret_cast<const uint4*>(p + PLANE_B);
-                    bl[nb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_B);
-                }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        f32x16 c = acc[mb][nb];
-                        c = mfma_bf16(al[mb], bh[nb], c);
-                        c = mfma_bf16(ah[mb], bl[nb], c);
-                        c = mfma_bf16(am[mb], bm[nb], c);
-                        c = mfma_bf16(am[mb], bh[nb], c);
-                        c = mfma_bf16(ah[mb], bm[nb], c);
-                        c = mfma_bf16(ah[mb], bh[nb], c);
-                        acc[mb][nb] = c;
-                    }
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-        have_c = have_n;
-        have_n = have_nn;
-    }
-
-    // ---- epilogue: consumer waves own the accumulators
-    if (!producer) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = n0 + wn * 64 + nb * 32 + li;
-            const bool cok = col < NC;
-            const float bv = (!DGRAD && a.bias != nullptr && cok) ? a.bias[col] : 0.f;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (cok && row < a.M) {
-                        float* o = &a.y[(size_t)row * a.ldy + col];
-                        *o = (DGRAD && a.accumulate) ? *o + acc[mb][nb][r] : acc[mb][nb][r] + bv;
-                    }
-                }
-        }
-    }
-    if (!DGRAD && a.stats != nullptr) {
-        float* red = reinterpret_cast<float*>(smem);  // [4][BN]
-        const int cnt = min(BM, a.M - m0);
-        if (!producer) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                float s = 0.f;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += acc[mb][nb][r];
-                s += __shfl_xor(s, 32);
-                if (lh == 0) red[wm * BN + wn * 64 + nb * 32 + li] = s;
-            }
-        }
-        __syncthreads();
-        if (!producer) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int c = wn * 64 + nb * 32 + li;
-                const float mean = (red[c] + red[BN + c]) / (float)cnt;
-                float qv = 0.f;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        float dv = acc[mb][nb][r] - mean;
-                        qv += row < a.M ? dv * dv : 0.f;
-                    }
-                qv += __shfl_xor(qv, 32);
-                if (lh == 0) red[(2 + wm) * BN + c] = qv;
-            }
-        }
-        __syncthreads();
-        if (t < BN && n0 + t < a.Cout) {
-            a.stats[(size_t)mt * a.Cout + n0 + t] = red[t] + red[BN + t];
-            a.stats[(size_t)(a.MT + mt) * a.Cout + n0 + t] = red[2 * BN + t] + red[3 * BN + t];
-        }
-    }
-}
-
-static int g_x6_ws = -1;
-static bool use_ws() {
-    if (g_x6_ws < 0) {
-        const char* e = getenv("ISWM_X6_WS");
-        g_x6_ws = (e && e[0] == '1') ? 1 : 0;   // experimental, off by default: no faster than the symmetric kernel
-    }
-    return g_x6_ws != 0;
-}
-
 // Tile choice for the bf16x6 forward / data-gradient kernels, from forced-tile sweeps over every
 // ResNet-101/DeepLabV3+ geometry (profiles/r01_x6_tile_sweep.txt): 128x64 runs 3 blocks per CU
 // (168 VGPRs) and wins almost everywhere; 64x64 (4 blocks per CU) wins when there are too few
@@ -609,11 +351,72 @@ bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn) {
     a.MT = (a.M + bm - 1) / bm;
     a.NT = (a.Cout + bn - 1) / bn;
     dim3 grid(a.MT * a.NT), blk(256);
-    if (bm == 128 && bn == 128 && use_ws()) hipLaunchKernelGGL((k_conv_x6ws<false>), grid, dim3(512), 0, s, a);
-    else if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_x6<128, 128, false>), grid, blk, 0, s, a);
-    else if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, false>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_conv_x6<64, 64, false>), grid, blk, 0, s, a);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_x6<128, 128, false, false>), grid, blk, 0, s, a);
+    else if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, false, false>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_conv_x6<64, 64, false, false>), grid, blk, 0, s, a);
     return true;
+}
+
+// packed-weight ("B direct") launchers: a.w = k_pack_weights_x6 output.  Tiles: 128x64 or 64x64.
+bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm) {
+    const int nc = dgrad ? a.Cin : a.Cout;
+    a.MT = (a.M + bm - 1) / bm;
+    a.NT = (nc + 63) / 64;
+    dim3 grid(a.MT * a.NT), blk(256);
+    if (dgrad) {
+        if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, true, true>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_conv_x6<64, 64, true, true>), grid, blk, 0, s, a);
+    } else {
+        if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, false, true>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_conv_x6<64, 64, false, true>), grid, blk, 0, s, a);
+    }
+    return true;
+}
+
+// Split + fragment-order packing of a conv weight for the B-direct kernels.
+//   fwd  : column = cout, k = (tap, cin)   from w[cout][tap][cin]
+//   dgrad: column = cin,  k = (tap, cout)  from the same tensor (implicit transpose)
+// packed[((cb * K16 + k16) * 3 + plane) * 64 + lane] (uint4) holds, for column cb*32 + (lane & 31), the 8 bf16 of
+// plane {hi, mid, lo} at k = k16*16 + 8*(lane >> 5) .. +7.  Columns >= NC are zero; cb runs to ceil(NC/64)*2.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void k_pack_weights_x6(const float* __restrict__ w, uint4* __restrict__ packed,
+                                                         int Cout, int T, int Cin, int K16, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, f = idx >> 6;
+    const int k16 = f % K16, cb = f / K16;
+    const int col = cb * 32 + (lane & 31), k0 = k16 * 16 + 8 * (lane >> 5);
+    const int NC = DGRAD ? Cin : Cout, GC = DGRAD ? Cout : Cin;
+    float v[8];
+    const int tap = k0 / GC, g0 = k0 - tap * GC;      // 8 consecutive k never straddle a tap (GC % 32 == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x = 0.f;
+        if (col < NC) x = DGRAD ? w[((size_t)(g0 + i) * T + tap) * Cin + col] : w[((size_t)col * T + tap) * Cin + g0 + i];
+        v[i] = x;
+    }
+    uint2 h0, m0, l0, h1, m1, l1;
+    split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+    split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+    uint4* o = packed + (size_t)f * 192 + lane;
+    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad) {
+    const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
+    const size_t cbs = (size_t)((NC + 63) / 64) * 2, K16 = (size_t)T * GC / 16;
+    return cbs * K16 * 192 * sizeof(uint4);
+}
+
+void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, hipStream_t s) {
+    const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
+    const int cbs = ((NC + 63) / 64) * 2, K16 = T * GC / 16;
+    const int total = cbs * K16 * 64;
+    dim3 grid((total + 255) / 256), blk(256);
+    if (dgrad) hipLaunchKernelGGL((k_pack_weights_x6<true>), grid, blk, 0, s, w, (uint4*)packed, Cout, T, Cin, K16, total);
+    else hipLaunchKernelGGL((k_pack_weights_x6<false>), grid, blk, 0, s, w, (uint4*)packed, Cout, T, Cin, K16, total);
 }
 
 // a: as prepared by iswm_conv2d_dgrad (a.x = dy with pitch a.ldx, a.y = dx with pitch a.ldy, a.M = N*H*W),
@@ -623,10 +426,9 @@ bool launch_conv_dgrad_x6(ConvArgs a, hipStream_t s, int bm, int bn) {
     a.MT = (a.M + bm - 1) / bm;
     a.NT = (a.Cin + bn - 1) / bn;
     dim3 grid(a.MT * a.NT), blk(256);
-    if (bm == 128 && bn == 128 && use_ws()) hipLaunchKernelGGL((k_conv_x6ws<true>), grid, dim3(512), 0, s, a);
-    else if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_x6<128, 128, true>), grid, blk, 0, s, a);
-    else if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, true>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_conv_x6<64, 64, true>), grid, blk, 0, s, a);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((k_conv_x6<128, 128, true, false>), grid, blk, 0, s, a);
+    else if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, true, false>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_conv_x6<64, 64, true, false>), grid, blk, 0, s, a);
     return true;
 }
 

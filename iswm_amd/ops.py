@@ -10,6 +10,7 @@ contiguous and whose pixel pitch ``ld = t.stride(2)`` may exceed C (a channel
 slice of a wider buffer -- that is how torch.cat disappears from the graph).
 """
 import ctypes
+import os
 
 import torch
 
@@ -201,9 +202,23 @@ def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
         lib = _lib.load()
         tiles = (lib.iswm_conv2d_stat_tiles(ctypes.byref(d)), lib.iswm_conv2d_stat_tile_rows(ctypes.byref(d)))
         partials = torch.empty((2, tiles[0], g.cout), dtype=torch.float32, device=x.device)
+    nb = _packed_bytes(d, 0)
+    if nb:
+        wpk = torch.empty((nb // 4,), dtype=torch.float32, device=x.device)
+        call("iswm_conv2d_pack_weights", ctypes.byref(d), 0, _p(w_ohwi), _p(wpk), _stream())
+        with _timed(d, 3, g):
+            call("iswm_conv2d_fwd_packed", ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(out), _p(partials), _stream())
+        return out, partials, tiles
     with _timed(d, 0, g):
         call("iswm_conv2d_fwd", ctypes.byref(d), _p(x), _p(w_ohwi), _p(bias), _p(out), _p(partials), _stream())
     return out, partials, tiles
+
+
+_USE_PACKED = os.environ.get("ISWM_X6_PK", "1") != "0"
+
+
+def _packed_bytes(d, kind):
+    return _lib.load().iswm_conv2d_packed_weight_bytes(ctypes.byref(d), kind) if _USE_PACKED else 0
 
 
 def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
@@ -215,6 +230,13 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
         dx = new_act(*x_like_shape, dy.device)
     ldx = geom(dx)[4]
     d = g.desc(ldx, ldy)
+    nb = _packed_bytes(d, 1)
+    if nb:
+        wpk = torch.empty((nb // 4,), dtype=torch.float32, device=dy.device)
+        call("iswm_conv2d_pack_weights", ctypes.byref(d), 1, _p(w_ohwi), _p(wpk), _stream())
+        with _timed(d, 4, g):
+            call("iswm_conv2d_dgrad_packed", ctypes.byref(d), _p(dy), _p(wpk), _p(dx), int(bool(accumulate)), _stream())
+        return dx
     if _lib.load().iswm_conv2d_dgrad_wants_wt(ctypes.byref(d)):
         # bf16x6 math: the matrix cores want the K axis (tap, cout) contiguous -> transposed weights
         wt = torch.empty((g.cin, g.kh, g.kw, g.cout), dtype=torch.float32, device=dy.device)

@@ -64,16 +64,19 @@ CONV_CASES = [
 
 @pytest.fixture
 def conv_math(request):
-    """run a test under one conv arithmetic (0 = exact fp32 MFMA, 1 = bf16x6) and restore the default"""
-    from iswm_amd import _lib
+    """run a test under one conv arithmetic (0 = exact fp32 MFMA, 1 = bf16x6 with pre-packed weight fragments,
+    2 = bf16x6 through the plain-weight entry points) and restore the default"""
+    from iswm_amd import _lib, ops
     lib = _lib.load()
-    old = lib.iswm_get_conv_math()
-    lib.iswm_set_conv_math(request.param)
+    old, old_pk = lib.iswm_get_conv_math(), ops._USE_PACKED
+    lib.iswm_set_conv_math(min(request.param, 1))
+    ops._USE_PACKED = request.param == 1
     yield request.param
     lib.iswm_set_conv_math(old)
+    ops._USE_PACKED = old_pk
 
 
-@pytest.mark.parametrize("conv_math", [0, 1], indirect=True, ids=["f32mfma", "bf16x6"])
+@pytest.mark.parametrize("conv_math", [0, 1, 2], indirect=True, ids=["f32mfma", "bf16x6", "bf16x6-plainw"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "cin%d_cout%d_k%d_s%d_d%d_h%d" % (c[0], c[1], c[2], c[3], c[5], c[6]))
 def test_conv_fwd_dgrad_wgrad(case, conv_math):
     from iswm_amd import ops
@@ -105,7 +108,7 @@ def test_conv_fwd_dgrad_wgrad(case, conv_math):
     assert rel_err(dw.cpu().permute(0, 3, 1, 2), wr.grad) < 5e-5
 
 
-@pytest.mark.parametrize("conv_math", [0, 1], indirect=True, ids=["f32mfma", "bf16x6"])
+@pytest.mark.parametrize("conv_math", [0, 1, 2], indirect=True, ids=["f32mfma", "bf16x6", "bf16x6-plainw"])
 def test_conv_pitched_slices_and_bias(conv_math):
     """reads a channel slice of a wider buffer and writes into a slice (torch.cat elimination)"""
     from iswm_amd import ops
