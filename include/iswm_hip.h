@@ -88,6 +88,11 @@ int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, const float* 
  * count -- Cin forward, Cout data gradient -- is not a multiple of 32). */
 size_t iswm_conv2d_packed_weight_bytes(const iswm_conv_desc* d, int kind);
 int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed, iswm_stream_t stream);
+/* layout of the BN partials iswm_conv2d_fwd_packed writes: tiles x Cout floats per plane (sum, centred M2).
+ * *tile_rows > 0: every tile holds that many rows (the last one the remainder); *tile_rows == 0: the tiles are
+ * image patches of varying size and their row counts follow the planes as floats (partials + 2*tiles*Cout), so
+ * the buffer is 2*tiles*Cout + tiles floats -- iswm_bn_finalize takes tile_rows = 0 for that layout. */
+int iswm_conv2d_fwd_packed_stat_layout(const iswm_conv_desc* d, int* tiles, int* tile_rows);
 int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, const void* wpk, const float* bias,
                            float* y, float* stat_partials, iswm_stream_t stream);
 int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy, const void* wpk, float* dx, int accumulate,

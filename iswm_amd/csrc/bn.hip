@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     double m2 = 0.0;
     if (c < C)
         for (int k = tl; k < tiles; k += TL) {
-            double nt = fmin(R, count - (double)k * R);
+            double nt = R > 0.0 ? fmin(R, count - (double)k * R) : (double)partials[(size_t)2 * tiles * C + k];
             double d = (double)partials[(size_t)k * C + c] / nt - mean;
             m2 += (double)partials[(size_t)(tiles + k) * C + c] + nt * d * d;
         }
@@ -359,7 +359,7 @@ extern "C" int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t
                                 float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                                 iswm_stream_t stream) {
     ISWM_REQUIRE(partials && scale && shift && save_mean && save_invstd && tiles > 0 && C > 0 && count > 0 &&
-                     tile_rows > 0 && (int64_t)tiles == (count + tile_rows - 1) / tile_rows,
+                     tile_rows >= 0 && (tile_rows == 0 || (int64_t)tiles == (count + tile_rows - 1) / tile_rows),
                  "bn_finalize: bad argument (tiles %d, count %lld, tile_rows %lld)", tiles, (long long)count,
                  (long long)tile_rows);
     if (tiles > 128)

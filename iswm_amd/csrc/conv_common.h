@@ -68,6 +68,28 @@ size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad);
 void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, hipStream_t s);
 void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s);
 
+// halo-patch bf16x6 kernel for stride-1 KxK filters (conv_mfma_x6p.hip)
+struct PatchArgs {
+    const float* x;      // gathered tensor (fwd: input x, dgrad: dy), NHWC with pitch ldg
+    const uint4* wpk;    // packed weights (k_pack_weights_x6)
+    const float* bias;   // fwd only, may be null
+    float* y;            // output tensor (fwd: y, dgrad: dx), pitch ldo
+    float* stats;        // fwd only: [2][MT][NC] tile sums / centred M2, then [MT] valid-row counts; may be null
+    int N, RH, RW;       // pixel grid of the GEMM rows (fwd: Ho x Wo, dgrad: H x W)
+    int GH, GW;          // pixel grid of the gathered tensor
+    int GC, NC;          // gathered channels (GEMM K per tap), output columns
+    int KH, KW, dil;
+    int orgh, orgw;      // gathered coordinate of halo (0,0) = patch origin + org
+    int flip;            // 1: tap (kh, kw) reads halo offset ((KH-1-kh)*dil, (KW-1-kw)*dil)  (data gradient)
+    int PH, PW, HH, HW;  // patch and halo dims
+    int TPY, TPX;        // patches per image
+    int ldg, ldo;
+    int MT, NT;
+    int accumulate;
+};
+bool conv_patch_plan(int RH, int RW, int KH, int KW, int dil, int* PH, int* PW);
+void launch_conv_x6_patch(PatchArgs a, bool dgrad, hipStream_t s);
+
 // tap-uniform fast path (conv_mfma_u.hip); each returns false when the geometry does not qualify
 bool launch_conv_fwd_u(ConvArgs a, hipStream_t s);
 void conv_pick_tile(int64_t M, int cols, int* bm, int* bn);

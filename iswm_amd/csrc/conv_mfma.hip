@@ -763,11 +763,43 @@ extern "C" int iswm_set_conv_math(int mode) {
 }
 extern "C" int iswm_get_conv_math(void) { return conv_math(); }
 
+// Halo-patch kernel applicability (stride-1 KxK, bf16x6, packed weights); ISWM_X6_PATCH=0 disables it.
+static int g_x6_patch = -1;
+static bool patch_plan(const iswm_conv_desc* d, bool dgrad, int* PH, int* PW) {
+    if (g_x6_patch < 0) {
+        const char* e = getenv("ISWM_X6_PATCH");
+        g_x6_patch = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!g_x6_patch || d->stride != 1 || d->KH * d->KW <= 1) return false;
+    return dgrad ? conv_patch_plan(d->H, d->W, d->KH, d->KW, d->dil, PH, PW)
+                 : conv_patch_plan(d->Ho, d->Wo, d->KH, d->KW, d->dil, PH, PW);
+}
+
+static PatchArgs patch_args(const iswm_conv_desc* d, bool dgrad, int PH, int PW) {
+    PatchArgs p{};
+    p.N = d->N;
+    p.KH = d->KH; p.KW = d->KW; p.dil = d->dil;
+    p.PH = PH; p.PW = PW;
+    if (!dgrad) {
+        p.RH = d->Ho; p.RW = d->Wo; p.GH = d->H; p.GW = d->W; p.GC = d->Cin; p.NC = d->Cout;
+        p.orgh = -d->pad; p.orgw = -d->pad; p.flip = 0; p.ldg = d->ldx; p.ldo = d->ldy;
+    } else {
+        p.RH = d->H; p.RW = d->W; p.GH = d->Ho; p.GW = d->Wo; p.GC = d->Cout; p.NC = d->Cin;
+        p.orgh = d->pad - d->dil * (d->KH - 1); p.orgw = d->pad - d->dil * (d->KW - 1);
+        p.flip = 1; p.ldg = d->ldy; p.ldo = d->ldx;
+    }
+    return p;
+}
+
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
     ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 4, "kernel_name: bad argument");
     if (kind >= 3) {   // 3 / 4: iswm_conv2d_fwd_packed / iswm_conv2d_dgrad_packed
         const bool dg = kind == 4;
         int pbm, pbn;
+        if (patch_plan(d, dg, &pbm, &pbn)) {
+            snprintf(buf, buflen, "k_conv_x6_patch<%s>", dg ? "true" : "false");
+            return 0;
+        }
         conv_pick_tile_x6(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, dg ? d->Cin : d->Cout,
                           d->KH * d->KW * (dg ? d->Cout : d->Cin), dg, d->KH * d->KW == 1, &pbm, &pbn);
         snprintf(buf, buflen, "k_conv_x6<%d, 64, %s, true>", pbm, dg ? "true" : "false");
@@ -899,6 +931,21 @@ extern "C" int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, co
     return check_launch("conv_dgrad_x6");
 }
 
+/* BN-partials layout of iswm_conv2d_fwd_packed: *tile_rows == 0 means the tiles are image patches with varying
+ * row counts, stored as floats after the two planes (partials + 2*tiles*Cout). */
+extern "C" int iswm_conv2d_fwd_packed_stat_layout(const iswm_conv_desc* d, int* tiles, int* tile_rows) {
+    ISWM_REQUIRE(d && tiles && tile_rows, "fwd_packed_stat_layout: null pointer");
+    int PH, PW;
+    if (patch_plan(d, false, &PH, &PW)) {
+        *tiles = d->N * ((d->Ho + PH - 1) / PH) * ((d->Wo + PW - 1) / PW);
+        *tile_rows = 0;
+    } else {
+        *tile_rows = iswm_conv2d_stat_tile_rows(d);
+        *tiles = iswm_conv2d_stat_tiles(d);
+    }
+    return 0;
+}
+
 /* ---- bf16x6 with pre-split, fragment-ordered weights ("packed"): kind 0 = forward, 1 = data gradient ---- */
 extern "C" size_t iswm_conv2d_packed_weight_bytes(const iswm_conv_desc* d, int kind) {
     if (!d || conv_math() != 1 || (kind != 0 && kind != 1)) return 0;
@@ -927,6 +974,13 @@ extern "C" int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, c
     a.x = x; a.w = reinterpret_cast<const float*>(wpk); a.bias = bias; a.y = y; a.stats = stat_partials;
     a.M = d->N * d->Ho * d->Wo;
     a.Ktot = d->KH * d->KW * d->Cin;
+    int PH, PW;
+    if (patch_plan(d, false, &PH, &PW)) {
+        PatchArgs p = patch_args(d, false, PH, PW);
+        p.x = x; p.wpk = reinterpret_cast<const uint4*>(wpk); p.bias = bias; p.y = y; p.stats = stat_partials;
+        launch_conv_x6_patch(p, false, (hipStream_t)stream);
+        return check_launch("conv_fwd_patch");
+    }
     int bm, bn;
     conv_pick_tile_x6(a.M, d->Cout, a.Ktot, false, d->KH * d->KW == 1, &bm, &bn);
     launch_conv_x6_pk(a, (hipStream_t)stream, false, bm);
@@ -944,6 +998,13 @@ extern "C" int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy
     a.ldx = d->ldy; a.ldy = d->ldx;
     a.M = d->N * d->H * d->W;
     a.Ktot = d->KH * d->KW * d->Cout;
+    int PH, PW;
+    if (patch_plan(d, true, &PH, &PW)) {
+        PatchArgs p = patch_args(d, true, PH, PW);
+        p.x = dy; p.wpk = reinterpret_cast<const uint4*>(wpk); p.y = dx; p.accumulate = accumulate;
+        launch_conv_x6_patch(p, true, (hipStream_t)stream);
+        return check_launch("conv_dgrad_patch");
+    }
     int bm, bn;
     conv_pick_tile_x6(a.M, d->Cin, a.Ktot, true, d->KH * d->KW == 1, &bm, &bn);
     launch_conv_x6_pk(a, (hipStream_t)stream, true, bm);

@@ -204,6 +204,12 @@ def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
         partials = torch.empty((2, tiles[0], g.cout), dtype=torch.float32, device=x.device)
     nb = _packed_bytes(d, 0)
     if nb:
+        if want_stats:
+            nt, tr = ctypes.c_int(0), ctypes.c_int(0)
+            call("iswm_conv2d_fwd_packed_stat_layout", ctypes.byref(d), ctypes.byref(nt), ctypes.byref(tr))
+            tiles = (nt.value, tr.value)
+            flat = torch.empty((2 * nt.value * g.cout + nt.value,), dtype=torch.float32, device=x.device)
+            partials = flat[:2 * nt.value * g.cout].view(2, nt.value, g.cout)   # per-tile row counts follow
         wpk = torch.empty((nb // 4,), dtype=torch.float32, device=x.device)
         call("iswm_conv2d_pack_weights", ctypes.byref(d), 0, _p(w_ohwi), _p(wpk), _stream())
         with _timed(d, 3, g):

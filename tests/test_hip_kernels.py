@@ -59,6 +59,12 @@ CONV_CASES = [
     (1280, 256, 1, 1, 0, 1, 17, 17, 2),     # ASPP projection: dgrad has 10 N-tiles x 5 M-tiles
     (1280, 256, 1, 1, 0, 1, 25, 25, 2),
     (512, 64, 1, 1, 0, 1, 17, 17, 2),
+    # stride-1 KxK with 32-aligned channels: the halo-patch bf16x6 kernel (patch shapes 11x11, 12x10, edge patches)
+    (64, 64, 3, 1, 1, 1, 33, 33, 3),
+    (96, 160, 3, 1, 1, 1, 40, 29, 2),
+    (64, 48, 3, 1, 0, 1, 21, 37, 2),        # pad 0: output smaller than input
+    (32, 64, 3, 1, 2, 2, 50, 50, 1),        # dilation 2
+    (64, 32, 5, 1, 2, 1, 23, 23, 2),        # 5x5
 ]
 
 
