@@ -33,14 +33,18 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
-# HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-# correction + WRITE_SIZE), see profiles/ -- filled in when a PMC profile of that kernel has been collected
-TRAFFIC_BYTES_PER_LAUNCH = {
-    # profiles/r01_pmc/wgrad_x6_layer3_3x3_{fetch,write}.csv: layer3 3x3 256->256 @33x33 batch 16 (22 of this
-    # kernel's 33 launches per step): FETCH_SIZE 109.2 MB x 2 (gfx950 wide-read correction) + WRITE_SIZE 32.3 MB
-    # vs 35.7 MB of operands + 33.0 MB of split-K slabs algorithmically (dy/x panels are re-read per tile pair)
-    "k_conv_wgrad<128, 128, 1, true>+reduce": 250.7e6,
-}
+# HBM bytes per launch of each kernel, averaged over the launches of one training step of THIS workload, from
+# two rocprofv3 PMC passes over tools/pmc_step.py (FETCH_SIZE, WRITE_SIZE; FETCH_SIZE doubled per the gfx950
+# wide-read correction of the MI355X guide), aggregated by tools/pmc_aggregate.py into profiles/.
+def pmc_traffic(kernel):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc", "step_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ent = table.get(kernel.replace("+reduce", ""))
+    return round(ent["hbm_bytes_per_launch"]) if ent else None
 
 
 def parse():
@@ -191,7 +195,19 @@ def main():
 
     # warm-up; its last step is profiled per conv kernel to find the dominant one, so that the timed region
     # only brackets THAT kernel's launches with events (bracketing all ~350 conv launches costs ~3 % of a step)
-    kprof, warm_summary = None, None
+    kprof, warm_summary, head_fwd = None, None, None
+    head = model.classifier
+    head_fwd_orig = head.fwd
+
+    def head_fwd_scoped(*a, **k):          # stamps the ASPP + decoder forward convs of the profiled warm-up step
+        if ops.KPROF is not None:
+            ops.KPROF.scope = "head_fwd"
+        try:
+            return head_fwd_orig(*a, **k)
+        finally:
+            if ops.KPROF is not None:
+                ops.KPROF.scope = None
+    head.fwd = head_fwd_scoped
     for i in range(args.warmup):
         if i == args.warmup - 1 and not args.no_kernel_timing:
             torch.cuda.synchronize()
@@ -200,6 +216,7 @@ def main():
     if ops.KPROF is not None:
         torch.cuda.synchronize()
         warm_summary = ops.KPROF.summary()
+        head_fwd = ops.KPROF.scope_total("head_fwd")
         ops.KPROF = None
         dominant = max(warm_summary.items(), key=lambda kv: kv[1]["ms"])[0]
         kprof = ops.KernelProfile(only=dominant)
@@ -266,7 +283,7 @@ def main():
                 "peak_basis": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 MAC (bf16x6)" if is_x6
                                else "fp32 MFMA dense peak"),
                 "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(name),
+                "traffic": pmc_traffic(name),
                 "launches": d["launches"], "avg_us": round(d["ms"] * 1e3 / d["launches"], 2),
                 "flops_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
             }
@@ -275,6 +292,13 @@ def main():
                     k: {"ms_per_step": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                         "launches_per_step": v["launches"]} for k, v in sorted(warm_summary.items())}
                 out["roofline"]["conv_ms_per_step_warmup"] = round(sum(v["ms"] for v in warm_summary.values()), 3)
+            if head_fwd is not None and head_fwd["ms"] > 0:
+                # north_star target: MFMA-roofline utilisation of the ASPP + decoder FORWARD convolutions
+                tf = head_fwd["flops"] / (head_fwd["ms"] * 1e-3) / 1e12
+                out["roofline"]["aspp_decoder_forward"] = {
+                    "launches": head_fwd["launches"], "ms": round(head_fwd["ms"], 3), "tflops": round(tf, 2),
+                    "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "frac_of_bf16x6_peak": round(tf / X6_PEAK_TFLOPS, 4) if math_name == "bf16x6" else None}
         if world == 1 and math_name == "bf16x6" and not args.no_alt:
             # same step with the exact-fp32 MFMA kernels, for reference (outside the timed region above)
             lib.iswm_set_conv_math(0)

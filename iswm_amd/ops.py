@@ -60,6 +60,7 @@ class KernelProfile:
     def __init__(self, only=None):
         self.records = []   # (kernel name, start event, end event, algorithmic flops, geometry tag)
         self.only = only    # when set: time launches of this kernel only (keeps the timed region light)
+        self.scope = None   # free-form label stamped on the records added while it is set (bench: "head_fwd")
 
     def begin(self):
         return True
@@ -72,12 +73,22 @@ class KernelProfile:
         return self.only is None or name == self.only or name + "+reduce" == self.only
 
     def add(self, name, a, b, flops, tag):
-        self.records.append((name, a, b, flops, tag))
+        self.records.append((name, a, b, flops, tag, self.scope))
+
+    def scope_total(self, scope):
+        """dict(launches, ms, flops) over the records stamped with this scope"""
+        d = dict(launches=0, ms=0.0, flops=0.0)
+        for name, a, b, fl, _, sc in self.records:
+            if sc == scope:
+                d["launches"] += 1
+                d["ms"] += a.elapsed_time(b)
+                d["flops"] += fl
+        return d
 
     def summary(self):
         """{name: dict(launches, ms, flops)} -- call after torch.cuda.synchronize()"""
         out = {}
-        for name, a, b, fl, _ in self.records:
+        for name, a, b, fl, _, _sc in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
             d["launches"] += 1
             d["ms"] += a.elapsed_time(b)
@@ -87,7 +98,7 @@ class KernelProfile:
     def by_geometry(self):
         """{(name, geometry tag): dict(launches, ms, flops)}"""
         out = {}
-        for name, a, b, fl, tag in self.records:
+        for name, a, b, fl, tag, _sc in self.records:
             d = out.setdefault((name, tag), dict(launches=0, ms=0.0, flops=0.0))
             d["launches"] += 1
             d["ms"] += a.elapsed_time(b)
