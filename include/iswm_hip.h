@@ -210,6 +210,43 @@ int iswm_loss_bwd_scale(float* grad, int64_t n, const float* sums, const float* 
 /* logits.max(1)[1], train.py:644,659 -- ties resolve to the lowest class index */
 int iswm_argmax_nchw(const float* logits, int B, int C, int64_t HW, int64_t* out, iswm_stream_t stream);
 
+/* ---- validation metrics ------------------------------------------------------------
+ * StreamMetrics._fast_hist, metrics/stream_metrics.py:24-31: hist[n_classes][n_classes] (int64, row = ground
+ * truth, column = prediction) += bincount(n_classes*label + pred) over the pixels whose label lies in
+ * [0, n_classes) (255 = ignore falls outside).  Exact integer counting; accumulates into hist.
+ * dtype codes: 0 = uint8, 1 = int64.  The _logits form takes the prediction as logits.max(1)[1]
+ * (train.py:644,659) without materialising the mask. */
+int iswm_confusion_matrix(const void* labels, int label_dtype, const void* preds, int pred_dtype, int64_t npix,
+                          int n_classes, int64_t* hist, iswm_stream_t stream);
+int iswm_confusion_matrix_logits(const void* labels, int label_dtype, const float* logits, int B, int C, int64_t HW,
+                                 int n_classes, int64_t* hist, iswm_stream_t stream);
+
+/* ---- training-input pipeline -------------------------------------------------------
+ * The reference's per-sample PIL chain ExtRandomScale -> ExtRandomCrop(pad_if_needed) -> ExtRandomHorizontalFlip ->
+ * ExtToTensor -> ExtNormalize (train.py:355-362, utils/ext_transforms.py:94-115,212-396) for a whole batch in one
+ * launch: uint8 HWC source images + uint8 HW labels in, normalised fp32 NCHW batch + uint8 label batch out.
+ * Bit-exact with Pillow's BILINEAR (image) / NEAREST (label) resize: the host computes Pillow's per-column /
+ * per-row bounds, 22-bit fixed-point weights and nearest-source indices (iswm_amd/utils/ext_transforms.py) and
+ * passes them in `tables`: per sample, at tab_off (ints):
+ *   xintab[rs_w] | yintab[rs_h] | hbounds[rs_w][2] (first source column, count) | hk[rs_w][ksize_h] |
+ *   vbounds[rs_h][2] | vk[rs_h][ksize_v].
+ * images / labels / samples / tables / outputs are device pointers; mean3 / std3 are HOST arrays of 3 floats. */
+typedef struct iswm_aug_sample {
+    long long img_off;      /* byte offset of this sample's uint8 [src_h][src_w][3] image in `images` */
+    long long lbl_off;      /* byte offset of its uint8 [src_h][src_w] label in `labels` */
+    int src_h, src_w;
+    int rs_h, rs_w;         /* size after the random rescale */
+    int pad;                /* border added on every side by pad_if_needed (0: none) */
+    int crop_i, crop_j;     /* crop origin (row, column) in the padded image */
+    int flip;               /* horizontal flip after the crop */
+    int tab_off;
+    int ksize_h, ksize_v;
+    int reserved;
+} iswm_aug_sample;
+int iswm_augment_batch(const unsigned char* images, const unsigned char* labels, const void* samples,
+                       const int* tables, int B, int crop_h, int crop_w, const float* mean3, const float* std3,
+                       float* out_nchw, unsigned char* out_labels, iswm_stream_t stream);
+
 /* ---- optimizers over a flat fp32 arena ------------------------------------------
  * torch.optim.SGD(momentum=0.9, nesterov=True, weight_decay) / Adam / AdamW as built
  * by setup_optimizer, train.py:421-444.  lr is read from device memory so that a

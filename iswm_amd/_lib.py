@@ -72,6 +72,9 @@ _SIGS = {
     "iswm_loss_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, P]),
     "iswm_loss_bwd_scale": (c_int, [P, c_int64, P, P, c_int, c_int64, P]),
     "iswm_argmax_nchw": (c_int, [P, c_int, c_int, c_int64, P, P]),
+    "iswm_augment_batch": (c_int, [P, P, P, P, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P, P]),
+    "iswm_confusion_matrix": (c_int, [P, c_int, P, c_int, c_int64, c_int, P, P]),
+    "iswm_confusion_matrix_logits": (c_int, [P, c_int, P, c_int, c_int, c_int64, c_int, P, P]),
     "iswm_sgd_step": (c_int, [P, P, P, c_int64, P, c_float, c_float, c_int, P]),
     "iswm_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_int, P]),
 }

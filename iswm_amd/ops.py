@@ -509,6 +509,39 @@ def argmax_nchw(logits):
     return out
 
 
+def _int_code(t):
+    if t.dtype == torch.uint8:
+        return 0
+    if t.dtype == torch.int64:
+        return 1
+    raise TypeError("expected a uint8 or int64 tensor, got %s" % t.dtype)
+
+
+def confusion_matrix(labels, preds, n_classes, hist=None):
+    """hist[n_classes, n_classes] (int64, device) += bincount(n_classes*label + pred) over valid labels"""
+    labels, preds = labels.contiguous(), preds.contiguous()
+    if labels.numel() != preds.numel():
+        raise ValueError("labels and predictions differ in size: %d vs %d" % (labels.numel(), preds.numel()))
+    if hist is None:
+        hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device=labels.device)
+    call("iswm_confusion_matrix", _p(labels), _int_code(labels), _p(preds), _int_code(preds), labels.numel(), n_classes,
+         _p(hist), _stream())
+    return hist
+
+
+def confusion_matrix_logits(labels, logits, n_classes, hist=None):
+    """the same with pred = logits.max(1)[1] computed on the fly (logits NCHW fp32)"""
+    labels, logits = labels.contiguous(), logits.contiguous()
+    b, c, h, w = logits.shape
+    if labels.numel() != b * h * w:
+        raise ValueError("labels %s do not match logits %s" % (tuple(labels.shape), tuple(logits.shape)))
+    if hist is None:
+        hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device=labels.device)
+    call("iswm_confusion_matrix_logits", _p(labels), _int_code(labels), _p(logits), b, c, h * w, n_classes, _p(hist),
+         _stream())
+    return hist
+
+
 def sgd_step(p, g, buf, lr_dev, momentum, weight_decay, nesterov):
     call("iswm_sgd_step", _p(p), _p(g), _p(buf), p.numel(), _p(lr_dev), float(momentum), float(weight_decay),
          int(bool(nesterov)), _stream())

@@ -76,6 +76,9 @@ def get_argparser():
                         choices=['spatial', 'temporal_p1', 'temporal_p2', 'temporal_p3', 'temporal_p4'])
     # additions
     parser.add_argument("--synthetic_len", type=int, default=256, help="tiles in the synthetic train split")
+    parser.add_argument("--device_augment", action='store_true', default=False,
+                        help="run the reference's train_transform (random scale / crop / flip / normalise, "
+                             "train.py:355-362) as one HIP kernel per batch on uint8 tiles")
     parser.add_argument("--pretrained_backbone", action='store_true', default=False)
     return parser
 
@@ -84,8 +87,9 @@ class SyntheticBinarySegmentation(data.Dataset):
     """Stand-in for the absent ``datasets.BinarySegmentation`` (train.py:14,371-380): ImageNet-normalised
     float32 [3,H,W] images, uint8 [H,W] labels in {0,1} with ~10 % foreground blobs, ``.images`` names."""
 
-    def __init__(self, root=None, split='train', transform=None, size=513, length=256, seed=0):
+    def __init__(self, root=None, split='train', transform=None, size=513, length=256, seed=0, raw=False):
         self.size, self.length, self.seed = size, length, seed + (0 if split == 'train' else 10_000)
+        self.raw = raw      # uint8 [H,W,3] source tiles for the device augmentation pipeline (--device_augment)
         self.images = ["synthetic_%s_%06d.png" % (split, i) for i in range(length)]
 
     def __len__(self):
@@ -97,6 +101,8 @@ class SyntheticBinarySegmentation(data.Dataset):
         img = torch.randn(3, s, s, generator=g)
         coarse = torch.rand(1, 1, (s + 31) // 32, (s + 31) // 32, generator=g)
         lab = (torch.nn.functional.interpolate(coarse, size=(s, s), mode='nearest')[0, 0] < 0.10).to(torch.uint8)
+        if self.raw:
+            img = (img.permute(1, 2, 0) * 58.0 + 116.0).clamp(0, 255).to(torch.uint8)     # what a decoded PNG tile holds
         return img, lab
 
     @staticmethod
@@ -108,7 +114,7 @@ def get_dataset(opts):
     if opts.dataset != 'synthetic':
         raise NotImplementedError("the BinarySegmentation dataset (DVC/S3, data.dvc) is not part of this build")
     return (SyntheticBinarySegmentation(split='train', size=opts.crop_size, length=opts.synthetic_len,
-                                        seed=opts.random_seed),
+                                        seed=opts.random_seed, raw=opts.device_augment),
             SyntheticBinarySegmentation(split='val', size=opts.crop_size, length=max(8, opts.val_batch_size * 2),
                                         seed=opts.random_seed))
 
@@ -153,29 +159,19 @@ def setup_criterion(opts, class_weights, group=None):
     return CrossEntropyLoss(weight=class_weights, ignore_index=255, reduction='mean', group=group)
 
 
-def confusion(preds, gts, n):
-    """2x2 (n x n) histogram of (gt, pred) -- StreamMetrics._fast_hist, metrics/stream_metrics.py"""
-    k = (gts >= 0) & (gts < n)
-    return torch.bincount(n * gts[k] + preds[k], minlength=n * n).reshape(n, n)
-
-
 def validate(model, loader, device, opts):
-    """train.py:620-666: eval-mode logits -> ``logits.max(1)[1]`` masks -> confusion-matrix scores."""
+    """train.py:620-666,686-694: eval-mode logits -> ``logits.max(1)[1]`` masks -> StreamMetrics scores.  The
+    argmax and the confusion matrix run in one kernel on the device (metrics.StreamMetrics.update_logits); no mask
+    is copied to the host."""
+    from .metrics import StreamMetrics
     model.eval()
-    hist = torch.zeros(opts.num_classes, opts.num_classes, dtype=torch.int64)
+    metrics = StreamMetrics(opts.num_classes, device=device)
     with torch.no_grad():
         for images, labels in loader:
             logits = model(images.to(device, dtype=torch.float32))
-            preds = ops.argmax_nchw(logits).cpu()
-            hist += confusion(preds.reshape(-1), labels.long().reshape(-1), opts.num_classes)
+            metrics.update_logits(labels.to(device), logits)
     model.train()
-    tp = hist.diag().double()
-    iou = tp / (hist.sum(0) + hist.sum(1) - hist.diag()).clamp(min=1).double()
-    prec = tp / hist.sum(0).clamp(min=1).double()
-    rec = tp / hist.sum(1).clamp(min=1).double()
-    f1 = 2 * prec * rec / (prec + rec).clamp(min=1e-12)
-    return {"MIoU": float(iou.mean()), "Foreground IoU": float(iou[1]), "Foreground F1": float(f1[1]),
-            "Precision": float(prec[1]), "Recall": float(rec[1])}
+    return {k: float(v) for k, v in metrics.get_results().items()}
 
 
 def save_best_model(model, optimizer, scheduler, opts, val_score, weighted_score, cur_itrs, best_score):
@@ -217,6 +213,17 @@ def main(argv=None):
     train_dst, val_dst = get_dataset(opts)
     sampler = data.distributed.DistributedSampler(train_dst, world, rank, shuffle=True, drop_last=True) \
         if world > 1 else None
+    train_transform = None
+    if opts.device_augment:
+        # the reference's train_transform (train.py:355-362) as one HIP kernel per batch over uint8 tiles on the GPU
+        from .utils import ext_transforms as et
+        train_transform = et.ExtCompose([
+            et.ExtRandomScale((0.5, 2.0)),
+            et.ExtRandomCrop(size=(opts.crop_size, opts.crop_size), pad_if_needed=True),
+            et.ExtRandomHorizontalFlip(),
+            et.ExtToTensor(),
+            et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]),
+        ])
     train_loader = data.DataLoader(train_dst, batch_size=opts.batch_size, shuffle=sampler is None, sampler=sampler,
                                    num_workers=2, drop_last=True)
     val_loader = data.DataLoader(val_dst, batch_size=opts.val_batch_size, shuffle=False, num_workers=0)
@@ -262,8 +269,12 @@ def main(argv=None):
             sampler.set_epoch(cur_epochs)
         for images, labels in train_loader:
             cur_itrs += 1
-            images = images.to(device, dtype=torch.float32, non_blocking=True)
-            labels = labels.to(device, non_blocking=True)
+            if train_transform is not None:
+                images, labels = train_transform.batch(list(images.to(device, non_blocking=True)),
+                                                       list(labels.to(device, non_blocking=True)))
+            else:
+                images = images.to(device, dtype=torch.float32, non_blocking=True)
+                labels = labels.to(device, non_blocking=True)
             logits = net(images)
             loss = criterion(logits, labels)
             optimizer.zero_grad()

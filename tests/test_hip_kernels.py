@@ -288,6 +288,61 @@ def test_argmax_bit_exact():
     assert torch.equal(out.cpu(), lg.max(1)[1])
 
 
+@pytest.mark.parametrize("ldt,pdt", [(torch.uint8, torch.int64), (torch.int64, torch.int64), (torch.uint8, torch.uint8),
+                                     (torch.int64, torch.uint8)])
+@pytest.mark.parametrize("nc", [2, 5])
+def test_confusion_matrix_bit_exact(ldt, pdt, nc):
+    """StreamMetrics._fast_hist (metrics/stream_metrics.py:24-31): exact counts, 255 and negative labels ignored,
+    accumulation over calls; full BASELINE mask size (16 x 513 x 513) in one of the cases"""
+    import numpy as np
+    from iswm_amd import ops
+    from oracle import metrics as ometrics
+    shape = (16, 513, 513) if (nc == 2 and ldt == torch.uint8 and pdt == torch.int64) else (3, 65, 47)
+    g = torch.Generator().manual_seed(11)
+    gt = torch.randint(0, nc, shape, generator=g)
+    gt[torch.rand(shape, generator=g) < 0.05] = 255
+    if ldt == torch.int64:
+        gt[0, 0, :7] = -1                                      # numpy masks negatives too
+    pr = torch.randint(0, nc, shape, generator=g)
+    ref = ometrics.fast_hist(gt.numpy(), pr.numpy(), nc)
+    hist = ops.confusion_matrix(gt.to(ldt).to(dev()) if ldt == torch.int64 else gt.clamp(min=0).to(ldt).to(dev()),
+                                pr.to(pdt).to(dev()), nc)
+    if ldt == torch.uint8:                                     # -1 is not representable: compare against the same data
+        ref = ometrics.fast_hist(gt.clamp(min=0).numpy(), pr.numpy(), nc)
+    assert hist.dtype == torch.int64 and np.array_equal(hist.cpu().numpy(), ref)
+    ops.confusion_matrix(gt.clamp(min=0).to(torch.uint8).to(dev()), pr.to(dev()), nc, hist=hist)
+    assert np.array_equal(hist.cpu().numpy(), ref + ometrics.fast_hist(gt.clamp(min=0).numpy(), pr.numpy(), nc))
+
+
+def test_stream_metrics_device_vs_oracle():
+    """iswm_amd.metrics.StreamMetrics: sequence / batch update semantics (:100-122), fused argmax from logits,
+    result keys and formulas (:33-63)"""
+    import numpy as np
+    from iswm_amd.metrics import StreamMetrics
+    from oracle import metrics as ometrics
+    g = torch.Generator().manual_seed(12)
+    logits = torch.randn(4, 2, 65, 65, generator=g)
+    logits[:, 1, :3] = logits[:, 0, :3]                        # ties -> class 0
+    gt = (torch.rand(4, 65, 65, generator=g) < 0.3).to(torch.uint8)
+    gt[:, 10:12] = 255
+    pred = logits.max(1)[1]
+    m = StreamMetrics(2)
+    m.update(gt.numpy(), pred.numpy(), sequence_data=True)     # a sequence contributes its last frame only
+    assert np.array_equal(m.confusion_matrix, ometrics.fast_hist(gt[-1].numpy(), pred[-1].numpy(), 2))
+    m.reset()
+    m.update(gt.to(dev()), pred.to(dev()), sequence_data=False)
+    ref = ometrics.fast_hist(gt.numpy(), pred.numpy(), 2)
+    assert np.array_equal(m.confusion_matrix, ref)
+    m2 = StreamMetrics(2)
+    m2.update_logits(gt.to(dev()), logits.to(dev()))
+    assert np.array_equal(m2.confusion_matrix, ref)
+    res, want = m.get_results(), ometrics.foreground_metrics(ref)
+    for key, w in zip(["MIoU", "Foreground IoU", "Precision", "Recall", "Foreground F1"], want):
+        assert abs(res[key] - w) <= 1e-12, key
+    with pytest.raises(TypeError):
+        m.update(gt.float(), pred, sequence_data=False)
+
+
 @pytest.mark.parametrize("oname", ["sgd", "adam", "adamw"])
 def test_optimizers_golden(oname):
     """torch.optim arithmetic with the arguments of train.py:421-452, 3 steps + cosine LR"""

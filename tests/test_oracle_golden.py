@@ -184,3 +184,18 @@ def test_cosine_lr_matches_torch():
         opt.step()
         sch.step()
         assert math.isclose(opt.param_groups[0]["lr"], ooptim.cosine_lr(1e-3, t, 50, 1e-4), rel_tol=1e-6)
+
+
+def test_confusion_matrix_metrics_hand_case():
+    """StreamMetrics._fast_hist / _calculate_foreground_metrics (metrics/stream_metrics.py:24-63) on a case
+    worked by hand: gt = [0,0,0,1,1,1,1,255], pred = [0,1,0,1,1,0,1,1] -> TN 2, FP 1, FN 1, TP 3 (255 ignored)."""
+    import numpy as np
+    from oracle import metrics as ometrics
+    gt = np.array([0, 0, 0, 1, 1, 1, 1, 255], dtype=np.uint8)
+    pr = np.array([0, 1, 0, 1, 1, 0, 1, 1], dtype=np.int64)
+    h = ometrics.fast_hist(gt, pr, 2)
+    assert h.tolist() == [[2, 1], [1, 3]]
+    miou, fiou, prec, rec, f1 = ometrics.foreground_metrics(h)
+    assert math.isclose(fiou, 3 / 5, rel_tol=1e-6) and math.isclose(prec, 0.75, rel_tol=1e-6)
+    assert math.isclose(rec, 0.75, rel_tol=1e-6) and math.isclose(f1, 0.75, rel_tol=1e-6)
+    assert math.isclose(miou, (2 / 4 + 3 / 5) / 2, rel_tol=1e-6)

@@ -30,3 +30,15 @@ def test_train_validate_checkpoint_resume(tmp_path, capsys):
     train.main(base + ["--total_itrs", "6", "--ckpt", files[0], "--continue_training"])
     out = capsys.readouterr().out
     assert "Model restored" in out and "Itrs 6/6" in out
+
+
+def test_train_with_device_augmentation(tmp_path, capsys):
+    """--device_augment: uint8 tiles -> one augmentation kernel per batch -> the same training loop; validation
+    goes through the fused argmax + confusion-matrix kernel"""
+    from iswm_amd import train
+    train.main(["--model", "deeplabv3plus_resnet50", "--crop_size", "65", "--batch_size", "4", "--synthetic_len", "16",
+                "--optimizer", "sgd", "--loss_type", "IWce_loss", "--print_interval", "2", "--val_interval", "3",
+                "--val_batch_size", "4", "--checkpoints_dir", str(tmp_path / "ck"), "--total_itrs", "3",
+                "--device_augment"])
+    out = capsys.readouterr().out
+    assert "Itrs 2/3" in out and "Validation @3" in out and "MIoU" in out
