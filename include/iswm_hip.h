@@ -97,6 +97,17 @@ int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, const void* 
                            float* y, float* stat_partials, iswm_stream_t stream);
 int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy, const void* wpk, float* dx, int accumulate,
                              iswm_stream_t stream);
+/* ---- depthwise convolution (groups == channels): first half of AtrousSeparableConvolution,
+ * network/_deeplab.py:95-119.  The descriptor has Cin == Cout == channel count of the (possibly zero-padded)
+ * activation; w is the torch parameter [Cw][1][KH][KW] as stored, Cw <= Cin (extra channels see zero weights).
+ * HBM-bound streaming kernels; the weight gradient reduces in a fixed order (workspace of doubles). */
+int iswm_dwconv2d_fwd(const iswm_conv_desc* d, const float* x, const float* w, int Cw, const float* bias, float* y,
+                      iswm_stream_t stream);
+int iswm_dwconv2d_dgrad(const iswm_conv_desc* d, const float* dy, const float* w, int Cw, float* dx, int accumulate,
+                        iswm_stream_t stream);
+size_t iswm_dwconv2d_wgrad_workspace(const iswm_conv_desc* d);
+int iswm_dwconv2d_wgrad(const iswm_conv_desc* d, const float* x, const float* dy, int Cw, float* dw, void* workspace,
+                        size_t workspace_bytes, iswm_stream_t stream);
 /* dw[Cout][KH][KW][Cin] = sum over pixels.  workspace holds split-K slabs. */
 size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d);
 int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const float* dy, float* dw,

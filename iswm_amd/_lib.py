@@ -39,6 +39,10 @@ _SIGS = {
     "iswm_conv2d_fwd_packed": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "iswm_conv2d_dgrad_packed": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
     "iswm_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "iswm_dwconv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
+    "iswm_dwconv2d_dgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, c_int, P]),
+    "iswm_dwconv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "iswm_dwconv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, c_size_t, P]),
     "iswm_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, P, P, c_size_t, P]),
     "iswm_colstat_tiles": (c_int, [c_int64]),
     "iswm_colstat_tile_rows": (c_int64, [c_int64]),

@@ -241,16 +241,62 @@ class _V3Bridge(torch.autograd.Function):
         return (None, ops.nhwc_to_nchw(d['out'], ctx.cin)) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
-class AtrousSeparableConvolution(nn.Module):
-    """Depthwise-separable rewrite (reference :95-119).  No entry point of the reference
-    ever builds it (convert_to_separable_conv is never called) and there is
-    no depthwise HIP kernel yet, so constructing it fails loudly instead of silently
-    running stock torch ops."""
+class AtrousSeparableConvolution(_hip.SeparableBase):
+    """Depthwise-separable conv (reference :95-119): body = [depthwise KxK conv (groups = in_channels), pointwise 1x1
+    conv], both with `bias`; no normalisation in between.  Same constructor, children and state_dict keys
+    (body.0.weight [Cin,1,K,K], body.1.weight [Cout,Cin,1,1], biases).  The depthwise half is an HBM-bound streaming
+    kernel (csrc/dwconv.hip), the pointwise half the ordinary implicit-GEMM conv."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
         super(AtrousSeparableConvolution, self).__init__()
-        raise NotImplementedError("AtrousSeparableConvolution needs a depthwise-conv HIP kernel (not built yet)")
+        self.body = _hip.HipSequential(
+            # Separable Conv
+            _hip.DepthwiseConv2d(in_channels, in_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                                 dilation=dilation, bias=bias, groups=in_channels),
+            # PointWise Conv
+            _hip.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0, bias=bias),
+        )
+        self._init_weight()
+
+    _init_weight = _init_weight
+
+    @property
+    def in_channels(self):
+        return self.body[1].in_channels
+
+    @property
+    def out_channels(self):
+        return self.body[1].out_channels
+
+    @property
+    def cin_p(self):
+        return self.body[1].cin_p
+
+    def fwd(self, x, save, out=None):
+        return self.body.fwd(x, save, out=out)
+
+    def bwd(self, dy, sink, need_dx=True, dx=None, accumulate=False):
+        return self.body.bwd(dy, sink, need_dx, dx, accumulate)
+
+    def out_channels_of(self, cin):
+        return self.body[1].out_channels
+
+    def forward(self, x):
+        return _hip.run_module(self, x)
 
 
 def convert_to_separable_conv(module):
-    raise NotImplementedError("convert_to_separable_conv needs a depthwise-conv HIP kernel (not built yet)")
+    """reference :176-188: every Conv2d with a kernel larger than 1 becomes an AtrousSeparableConvolution with the
+    same geometry (fresh weights); children are carried over."""
+    new_module = module
+    if isinstance(module, nn.Conv2d) and not isinstance(module, _hip.DepthwiseConv2d) and module.kernel_size[0] > 1:
+        new_module = AtrousSeparableConvolution(module.in_channels,
+                                                module.out_channels,
+                                                module.kernel_size,
+                                                module.stride,
+                                                module.padding,
+                                                module.dilation,
+                                                module.bias)
+    for name, child in module.named_children():
+        new_module.add_module(name, convert_to_separable_conv(child))
+    return new_module

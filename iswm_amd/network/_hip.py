@@ -221,6 +221,53 @@ class Conv2d(HipModule, nn.Conv2d):
         return self.out_channels
 
 
+class DepthwiseConv2d(HipModule, nn.Conv2d):
+    """nn.Conv2d(C, C, k, groups=C): the depthwise half of AtrousSeparableConvolution (network/_deeplab.py:103).
+    The parameter keeps torch's [C,1,KH,KW] layout; the activation may be a zero-padded buffer wider than C."""
+
+    def __init__(self, *args, **kwargs):
+        nn.Conv2d.__init__(self, *args, **kwargs)
+        if self.groups != self.in_channels or self.out_channels != self.in_channels or self.padding_mode != "zeros":
+            raise NotImplementedError("HIP depthwise conv needs groups == in_channels == out_channels, zero padding")
+        if self.kernel_size[0] != self.kernel_size[1] or self.dilation[0] != self.dilation[1] or \
+                self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError("HIP depthwise conv supports square kernels/strides/dilations")
+        self._saved = None
+
+    def geometry(self, x):
+        c = x.shape[3]
+        if c < self.in_channels or c % 4 != 0:
+            raise ValueError("depthwise conv over %d channels got a %d-channel buffer" % (self.in_channels, c))
+        return ops.ConvGeom(x, c, self.kernel_size[0], self.kernel_size[1], self.stride[0], self.padding[0],
+                            self.dilation[0])
+
+    def fwd(self, x, save, out=None):
+        g = self.geometry(x)
+        y = ops.dwconv2d_fwd(x, self.weight.contiguous(), g, self.bias, out)
+        self._saved = (x, g) if save else None
+        return y
+
+    def bwd(self, dy, sink, need_dx=True, dx=None, accumulate=False):
+        x, g = self._saved
+        self._saved = None
+        if self.bias is not None and self.bias.requires_grad:
+            sink.target(self.bias).copy_(ops.colsum(dy)[:self.out_channels])
+            sink.done(self.bias)
+        if self.weight.requires_grad:
+            buf = sink.target(self.weight)
+            if buf.is_contiguous():
+                ops.dwconv2d_wgrad(x, dy, g, self.in_channels, buf)
+            else:
+                buf.copy_(ops.dwconv2d_wgrad(x, dy, g, self.in_channels))
+            sink.done(self.weight)
+        if not need_dx:
+            return None
+        return ops.dwconv2d_dgrad(dy, self.weight.contiguous(), g, tuple(x.shape), dx, accumulate)
+
+    def out_channels_of(self, cin):
+        return self.out_channels
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     pass
 
@@ -260,11 +307,24 @@ class Dropout(HipModule, nn.Dropout):
 def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
     """Returns (out, ctx).  Training-mode BN statistics come from the conv epilogue's
     per-tile partial sums (no extra pass over y)."""
+    sep = None
+    if isinstance(conv, SeparableBase):         # depthwise first, then the pointwise conv carries the fused BN
+        sep, conv = conv, conv.body[1]
+        x = sep.body[0].fwd(x, save)
     g = conv.geometry(x)
     training = bn.training
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise NotImplementedError("HIP BatchNorm2d supports affine=True, momentum!=None, running stats")
-    y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training)
+    if conv.bias is None:
+        y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training)
+    else:
+        # a biased conv in front of a BatchNorm (only reachable through convert_to_separable_conv on a biased
+        # conv): the fused epilogue statistics do not include the bias, so take them in a separate column pass
+        y, _, _ = ops.conv2d_fwd(x, conv.ohwi(), g, bias=conv.bias_p())
+        partials, tiles = None, (0, 0)
+        if training:
+            partials, nt, tr = ops.colstat(y)
+            tiles = (nt, tr)
     if training:
         count = y.shape[0] * y.shape[1] * y.shape[2]
         if count <= 1:
@@ -282,13 +342,16 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
         MASK_RECORDER[bn] = (o > 0)
     ctx = None
     if save:
-        ctx = dict(x=x, y=y, out=o, coef=coef, g=g, relu=relu, training=training, res=residual is not None)
+        ctx = dict(x=x, y=y, out=o, coef=coef, g=g, relu=relu, training=training, res=residual is not None, sep=sep)
     return o, ctx
 
 
 def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
     """Returns (dx, dres): dres is the gradient of the residual input (if any)."""
     x, y, o, g = ctx["x"], ctx["y"], ctx["out"], ctx["g"]
+    sep = ctx.get("sep")
+    if sep is not None:
+        conv = sep.body[1]
     gw, gb = bn.weight, bn.bias
     dgamma = sink.target(gw) if gw.requires_grad else torch.empty_like(gw)
     dbeta = sink.target(gb) if gb.requires_grad else torch.empty_like(gb)
@@ -299,6 +362,12 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
     if gb.requires_grad:
         sink.done(gb)
     conv.write_wgrad(x, dy, g, sink)
+    if conv.bias is not None and conv.bias.requires_grad:
+        sink.target(conv.bias).copy_(ops.colsum(dy)[:conv.out_channels])
+        sink.done(conv.bias)
+    if sep is not None:
+        dmid = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape))
+        return sep.body[0].bwd(dmid, sink, need_dx, dx, accumulate), dres
     if need_dx:
         dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate)
     else:
@@ -320,6 +389,12 @@ def fuse_batch_counters(root):
     return flat
 
 
+class SeparableBase(HipModule):
+    """marker base of _deeplab.AtrousSeparableConvolution (body = [DepthwiseConv2d, pointwise Conv2d]) so that the
+    conv -> BN -> ReLU stage logic here can recognise it without importing _deeplab"""
+    pass
+
+
 class HipSequential(HipModule, nn.Sequential):
     """nn.Sequential whose children are grouped into fused stages:
     [Conv2d, BatchNorm2d, ReLU?] -> cba;  Conv2d alone -> conv(+bias);  Dropout;  HipModule."""
@@ -329,7 +404,11 @@ class HipSequential(HipModule, nn.Sequential):
         st, i = [], 0
         while i < len(mods):
             m = mods[i]
-            if isinstance(m, Conv2d):
+            if isinstance(m, (Conv2d, SeparableBase)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                st.append(("cba", m, mods[i + 1], relu))
+                i += 3 if relu else 2
+            elif isinstance(m, Conv2d):
                 if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
                     relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
                     st.append(("cba", m, mods[i + 1], relu))

@@ -280,6 +280,37 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
     return dw_ohwi
 
 
+# ---- depthwise conv (groups == channels) -------------------------------------------------------------
+def dwconv2d_fwd(x, w, g, bias=None, out=None):
+    """x NHWC [N,H,W,C]; w the parameter [Cw,1,KH,KW] (contiguous), Cw <= C"""
+    ldx = geom(x)[4]
+    if out is None:
+        out = new_act(g.n, g.ho, g.wo, g.cin, x.device)
+    d = g.desc(ldx, geom(out)[4])
+    call("iswm_dwconv2d_fwd", ctypes.byref(d), _p(x), _p(w), w.shape[0], _p(bias), _p(out), _stream())
+    return out
+
+
+def dwconv2d_dgrad(dy, w, g, x_like_shape, dx=None, accumulate=False):
+    if dx is None:
+        assert not accumulate
+        dx = new_act(*x_like_shape, dy.device)
+    d = g.desc(geom(dx)[4], geom(dy)[4])
+    call("iswm_dwconv2d_dgrad", ctypes.byref(d), _p(dy), _p(w), w.shape[0], _p(dx), int(bool(accumulate)), _stream())
+    return dx
+
+
+def dwconv2d_wgrad(x, dy, g, cw, dw=None):
+    """dw [Cw,1,KH,KW]"""
+    if dw is None:
+        dw = torch.empty((cw, 1, g.kh, g.kw), dtype=torch.float32, device=x.device)
+    d = g.desc(geom(x)[4], geom(dy)[4])
+    need = _lib.load().iswm_dwconv2d_wgrad_workspace(ctypes.byref(d))
+    ws = torch.empty((need // 8,), dtype=torch.float64, device=x.device)
+    call("iswm_dwconv2d_wgrad", ctypes.byref(d), _p(x), _p(dy), cw, _p(dw), _p(ws), need, _stream())
+    return dw
+
+
 def rows(t):
     n, h, w, c, ld = geom(t)
     return n * h * w, c, ld

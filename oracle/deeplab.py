@@ -155,3 +155,13 @@ class OracleDeepLab:
 def argmax_mask(logits):
     """``logits.max(1)[1]`` -- train.py:644,659; ties resolve to the lowest index."""
     return logits.max(1)[1]
+
+
+def sepconv_forward(x, sd, prefix, stride, padding, dilation):
+    """AtrousSeparableConvolution.forward (network/_deeplab.py:95-111): depthwise KxK conv (groups = channels,
+    weight sd[prefix + 'body.0.weight'] of shape [C,1,K,K]) followed by a pointwise 1x1 conv; both carry the
+    optional biases body.{0,1}.bias."""
+    import torch.nn.functional as F
+    w0, w1 = sd[prefix + "body.0.weight"], sd[prefix + "body.1.weight"]
+    y = F.conv2d(x, w0, sd.get(prefix + "body.0.bias"), stride, padding, dilation, groups=w0.shape[0])
+    return F.conv2d(y, w1, sd.get(prefix + "body.1.bias"))

@@ -311,16 +311,64 @@ def gen_optim(outdir):
     np.savez_compressed(os.path.join(outdir, "optim.npz"), **out)
 
 
+SEPCONV_CASES = OrderedDict([
+    # tag: (cin, cout, k, stride, padding, dilation, bias, H, W)
+    ("k3_d2_bias", (16, 24, 3, 1, 2, 2, True, 13, 11)),
+    ("k3_s2_nobias", (32, 16, 3, 2, 1, 1, False, 17, 17)),
+    ("k5_d1_bias", (8, 12, 5, 1, 2, 1, True, 9, 14)),
+])
+
+
+def gen_sepconv(deeplab, outdir):
+    """AtrousSeparableConvolution (network/_deeplab.py:95-119) and convert_to_separable_conv (:176-188) applied to
+    an ASPPConv (conv -> BN -> ReLU with the conv replaced by depthwise + pointwise)."""
+    out = {}
+    for tag, (cin, cout, k, s, p, d, bias, h, w) in SEPCONV_CASES.items():
+        m = load_synth(deeplab.AtrousSeparableConvolution(cin, cout, k, s, p, d, bias), "sep.%s." % tag)
+        x = synth_images(2, h, w, seed=31, c=cin)
+        xg = x.clone().requires_grad_(True)
+        y = m(xg)
+        pack(out, tag + ".out", y)
+        (y * upstream(y.shape, 7)).sum().backward()
+        pack(out, tag + ".grad_x", xg.grad)
+        for n, prm in m.named_parameters():
+            out["%s.grad.%s" % (tag, n)] = prm.grad.detach().numpy().copy()
+    m = deeplab.convert_to_separable_conv(deeplab.ASPPConv(32, 16, 3))
+    assert isinstance(m[0], deeplab.AtrousSeparableConvolution)
+    m = load_synth(m, "sep.asppconv.")
+    x = synth_images(4, 19, 19, seed=32, c=32)
+    m.eval()
+    pack(out, "asppconv.eval_out", m(x))
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    y = m(xg)
+    pack(out, "asppconv.train_out", y)
+    (y * upstream(y.shape, 8)).sum().backward()
+    pack(out, "asppconv.grad_x", xg.grad)
+    for n, prm in m.named_parameters():
+        out["asppconv.grad.%s" % n] = prm.grad.detach().numpy().copy()
+    for kk, v in m.state_dict().items():
+        if "running" in kk:
+            out["asppconv.buf." + kk] = v.numpy().copy()
+    out["asppconv.keys"] = np.array(list(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(outdir, "sepconv.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     ap.add_argument("--skip-model", action="store_true")
+    ap.add_argument("--only", default=None, help="generate just this fixture group (e.g. sepconv)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     modeling, deeplab, resnet, loss = import_reference(args.ref)
+    if args.only == "sepconv":
+        gen_sepconv(deeplab, args.out)
+        return
+    gen_sepconv(deeplab, args.out)
     gen_aspp(deeplab, args.out)
     gen_head(deeplab, args.out)
     gen_bottleneck(resnet, args.out)

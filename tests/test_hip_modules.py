@@ -370,3 +370,112 @@ def test_full_size_properties():
     with torch.no_grad():
         lg = m(x)
     assert torch.equal(ops.argmax_nchw(lg).cpu(), lg.cpu().max(1)[1])
+
+
+@pytest.mark.parametrize("os_,size", [(8, 769), (16, 1024)], ids=["r101_os8_769", "r101_os16_1024"])
+def test_baseline_large_tile_configs(os_, size):
+    """BASELINE.json configs[3] / configs[4] geometry (resnet101, output_stride 8 at 769x769 with ASPP rates
+    12/24/36, and output_stride 16 at 1024x1024), batch 2: one training step is finite, repeats bit-identically,
+    and the two conv arithmetics agree on the loss to well under the 1e-3 contract."""
+    from iswm_amd import _lib
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle.synth import synth_images, synth_labels
+    m, cfg, sd = _build("resnet101", os_)
+    x = synth_images(2, size, size, seed=9).to(dev())
+    lab = synth_labels(2, size, size, seed=9).to(dev())
+    m.train()
+    lib = _lib.load()
+    crit = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]))
+    res = []
+    for math in (lib.iswm_get_conv_math(), lib.iswm_get_conv_math(), 0):
+        old = lib.iswm_get_conv_math()
+        lib.iswm_set_conv_math(math)
+        try:
+            m.load_state_dict(sd, strict=True)
+            lg = m(x)
+            assert lg.shape == (2, 2, size, size) and bool(torch.isfinite(lg).all())
+            loss = crit(lg, lab)
+            for p in m.parameters():
+                p.grad = None
+            loss.backward()
+            g = m.backbone.layer3[0].conv2.weight.grad
+            assert bool(torch.isfinite(g).all())
+            res.append((float(loss), lg.detach().clone(), g.clone()))
+        finally:
+            lib.iswm_set_conv_math(old)
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])     # bit-identical repeat
+    assert abs(res[0][0] - res[2][0]) <= 1e-4 * abs(res[2][0])                          # bf16x6 vs exact fp32 MFMA
+
+
+def test_separable_conv_and_conversion():
+    """AtrousSeparableConvolution and convert_to_separable_conv (network/_deeplab.py:95-119,176-188) vs vectors
+    produced by the reference's own classes: same state_dict keys, forward and every gradient."""
+    from iswm_amd.network import _deeplab, _hip
+    from oracle.make_golden import SEPCONV_CASES
+    from oracle.synth import synth_images, synth_tensor
+    fx = load("sepconv.npz")
+    for tag, (cin, cout, k, s, p, d, bias, h, w) in SEPCONV_CASES.items():
+        m = _deeplab.AtrousSeparableConvolution(cin, cout, k, s, p, d, bias)
+        pre = "sep.%s." % tag
+        m.load_state_dict(OrderedDict((key, synth_tensor(pre + key, tuple(v.shape))) for key, v in m.state_dict().items()),
+                          strict=True)
+        m = m.to(dev())
+        xg = synth_images(2, h, w, seed=31, c=cin).to(dev()).requires_grad_(True)
+        y = m(xg)
+        check(y, fx, tag + ".out")
+        (y * upstream(y.shape, 7).to(dev())).sum().backward()
+        check(xg.grad, fx, tag + ".grad_x")
+        for key, prm in m.named_parameters():
+            assert rel_err(prm.grad, fx["%s.grad.%s" % (tag, key)]) <= RTOL, (tag, key)
+    # conversion of a conv -> BN -> ReLU stage
+    m = _deeplab.convert_to_separable_conv(_deeplab.ASPPConv(32, 16, 3))
+    assert isinstance(m[0], _deeplab.AtrousSeparableConvolution) and isinstance(m[0].body[0], _hip.DepthwiseConv2d)
+    assert list(m.state_dict().keys()) == [str(s_) for s_ in fx["asppconv.keys"]]
+    m.load_state_dict(OrderedDict((key, synth_tensor("sep.asppconv." + key, tuple(v.shape)))
+                                  for key, v in m.state_dict().items()), strict=True)
+    m = m.to(dev())
+    x = synth_images(4, 19, 19, seed=32, c=32)
+    m.eval()
+    with torch.no_grad():
+        check(m(x.to(dev())), fx, "asppconv.eval_out")
+    m.train()
+    xg = x.to(dev()).requires_grad_(True)
+    y = m(xg)
+    check(y, fx, "asppconv.train_out")
+    (y * upstream(y.shape, 8).to(dev())).sum().backward()
+    check_robust(xg.grad, fx, "asppconv.grad_x")
+    for key, prm in m.named_parameters():
+        check_grad_robust(prm.grad, fx, "asppconv.grad." + key)
+    for key in ("1.running_mean", "1.running_var"):
+        assert rel_err(m.state_dict()[key], fx["asppconv.buf." + key]) <= RTOL, key
+
+
+def test_converted_head_trains():
+    """network.convert_to_separable_conv(model.classifier) -- the upstream use of the function -- yields a model
+    that steps: ASPP branches and both decoder 3x3s become depthwise + pointwise (decoder input stays the padded
+    320-wide concat buffer), logits and all gradients finite, repeat bit-identical."""
+    from iswm_amd.network import _deeplab
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle.synth import synth_images, synth_labels
+    m, cfg, sd = _build("resnet50", 16)
+    m.classifier = _deeplab.convert_to_separable_conv(m.classifier).to(dev())
+    assert isinstance(m.classifier.classifier[0], _deeplab.AtrousSeparableConvolution)
+    assert isinstance(m.classifier.aspp.convs[1][0], _deeplab.AtrousSeparableConvolution)
+    m.classifier.aspp.project[3].p = 0.0
+    x = synth_images(4, 65, 65, seed=3).to(dev())
+    lab = synth_labels(4, 65, 65, seed=3).to(dev())
+    m.train()
+    crit = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]))
+    init = {k: v.clone() for k, v in m.state_dict().items()}
+    outs = []
+    for _ in range(2):
+        m.load_state_dict(init, strict=True)
+        for p in m.parameters():
+            p.grad = None
+        lg = m(x)
+        assert lg.shape == (4, 2, 65, 65) and bool(torch.isfinite(lg).all())
+        crit(lg, lab).backward()
+        gs = [p.grad.clone() for p in m.parameters()]
+        assert all(bool(torch.isfinite(g).all()) for g in gs) and all(float(g.abs().max()) > 0 for g in gs)
+        outs.append((lg.detach().clone(), gs))
+    assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))

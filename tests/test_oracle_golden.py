@@ -199,3 +199,25 @@ def test_confusion_matrix_metrics_hand_case():
     assert math.isclose(fiou, 3 / 5, rel_tol=1e-6) and math.isclose(prec, 0.75, rel_tol=1e-6)
     assert math.isclose(rec, 0.75, rel_tol=1e-6) and math.isclose(f1, 0.75, rel_tol=1e-6)
     assert math.isclose(miou, (2 / 4 + 3 / 5) / 2, rel_tol=1e-6)
+
+
+def test_separable_conv_golden():
+    """AtrousSeparableConvolution (network/_deeplab.py:95-119) restated in oracle/deeplab.py vs the reference"""
+    from oracle.deeplab import sepconv_forward
+    from oracle.make_golden import SEPCONV_CASES, upstream
+    from oracle.synth import synth_images, synth_tensor
+    fx = load("sepconv.npz")
+    for tag, (cin, cout, k, s, p, d, bias, h, w) in SEPCONV_CASES.items():
+        pre = "sep.%s." % tag
+        sd = {pre + "body.0.weight": synth_tensor(pre + "body.0.weight", (cin, 1, k, k)).requires_grad_(True),
+              pre + "body.1.weight": synth_tensor(pre + "body.1.weight", (cout, cin, 1, 1)).requires_grad_(True)}
+        if bias:
+            sd[pre + "body.0.bias"] = synth_tensor(pre + "body.0.bias", (cin,)).requires_grad_(True)
+            sd[pre + "body.1.bias"] = synth_tensor(pre + "body.1.bias", (cout,)).requires_grad_(True)
+        x = synth_images(2, h, w, seed=31, c=cin).requires_grad_(True)
+        y = sepconv_forward(x, sd, pre, s, p, d)
+        assert rel_err(y, fx[tag + ".out"]) <= 2e-6, tag
+        (y * upstream(y.shape, 7)).sum().backward()
+        assert rel_err(x.grad, fx[tag + ".grad_x"]) <= 2e-6, tag
+        for key, t in sd.items():
+            assert rel_err(t.grad, fx["%s.grad.%s" % (tag, key[len(pre):])]) <= 2e-6, (tag, key)
