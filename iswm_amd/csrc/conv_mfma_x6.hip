@@ -24,6 +24,35 @@ static __device__ __attribute__((aligned(16))) float g_zero_row_x[64];
 
 constexpr int X6_PITCH = 80;   // bytes per LDS row of one bf16 plane (32 k x 2 B + 16 B pad)
 
+// GEMM row m -> pixel (n, rh, rw) of an N x RH x RW grid.  par == false: row-major.  par == true (data gradient of
+// a stride-2 conv): rows are grouped by the PARITY class (rh & 1, rw & 1) of the pixel -- classes (0,0), (0,1),
+// (1,0), (1,1), each row-major over (n, rh >> 1, rw >> 1) -- because a tap (kh, kw) only reaches input pixels of one
+// parity class: with uniform-parity tiles the per-tile tap culling drops the 3/4 (1x1) or ~5/9..8/9 (3x3) of the taps
+// that would gather nothing but zeros.
+__device__ __forceinline__ void x6_row_pixel(int m, int N, int RH, int RW, bool par, int& n, int& rh, int& rw) {
+    if (!par) {
+        const int RHW = RH * RW;
+        n = m / RHW;
+        const int rem = m - n * RHW;
+        rh = rem / RW;
+        rw = rem - rh * RW;
+        return;
+    }
+    const int H0 = (RH + 1) >> 1, H1 = RH >> 1, W0 = (RW + 1) >> 1, W1 = RW >> 1;
+    const int o1 = N * H0 * W0, o2 = o1 + N * H0 * W1, o3 = o2 + N * H1 * W0;
+    int ph, pw, r;
+    if (m < o1) { ph = 0; pw = 0; r = m; }
+    else if (m < o2) { ph = 0; pw = 1; r = m - o1; }
+    else if (m < o3) { ph = 1; pw = 0; r = m - o2; }
+    else { ph = 1; pw = 1; r = m - o3; }
+    const int Hc = ph ? H1 : H0, Wc = pw ? W1 : W0, S = Hc * Wc;
+    n = r / S;
+    const int rem = r - n * S;
+    const int i = rem / Wc;
+    rh = 2 * i + ph;
+    rw = 2 * (rem - i * Wc) + pw;
+}
+
 // DGRAD == false: forward.  rows = output pixels, A = x gathered per tap, B = OHWI weights [cout][(tap, cin)].
 // DGRAD == true : data gradient.  rows = INPUT pixels, A = dy gathered per tap (a.x = dy, pitch a.ldx),
 //                 B = TRANSPOSED weights [cin][(tap, cout)] (iswm_transpose_weights), output a.y = dx.
@@ -44,7 +73,15 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = L / a.NT, nt = L - mt * a.NT;
+    int mt = L / a.NT;
+    const int nt = L - mt * a.NT;
+    if (DGRAD && a.stride == 2 && a.nsplit == 0) {
+        // parity-ordered rows (below): the four parity classes occupy consecutive quarters of the M tiles and do very
+        // different amounts of work (a 1x1 reaches one class only), while xcd_remap hands each XCD one contiguous run
+        // of tiles -- deal the tiles out so every run holds all four quarters:  mt = 4*idx + k  ->  quarter k, slot idx
+        const int qn = a.MT >> 2, rem = a.MT & 3, k = mt & 3, idx = mt >> 2;
+        mt = k * qn + (k < rem ? k : rem) + idx;
+    }
     const int m0 = mt * BM, n0 = nt * BN;
 #if defined(ISWM_X6_V1)
     const int q = t & 7, idx_ = t >> 3;
@@ -60,14 +97,21 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
     // row -> pixel of the tensor the rows live in (fwd: output Ho x Wo; dgrad: input H x W)
     const int RH = DGRAD ? a.H : a.Ho, RW = DGRAD ? a.W : a.Wo;
     const int GH = DGRAD ? a.Ho : a.H, GW = DGRAD ? a.Wo : a.W;     // gathered tensor dims
-    const int RHW = RH * RW;
+    const bool par = DGRAD && a.stride == 2 && a.nsplit == 0;     // a.nsplit != 0: tuning switch, row-major rows
+    __shared__ int rowpix[DGRAD ? BM : 1];       // parity order: output pixel of each tile row
+    if (DGRAD && par && t < BM) {
+        const int m = m0 + t;
+        int n = 0, rh = 0, rw = 0;
+        if (m < a.M) x6_row_pixel(m, a.N, RH, RW, true, n, rh, rw);
+        rowpix[DGRAD ? t : 0] = (n * RH + rh) * RW + rw;
+    }
     int ihb[AR], iwb[AR], pb[AR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         int m = m0 + r0 + 32 * j;
         if (m < a.M) {
-            int n = m / RHW, rem = m - n * RHW;
-            int rh = rem / RW, rw = rem - rh * RW;
+            int n, rh, rw;
+            x6_row_pixel(m, a.N, RH, RW, par, n, rh, rw);
             ihb[j] = DGRAD ? rh + a.pad : rh * a.stride - a.pad;
             iwb[j] = DGRAD ? rw + a.pad : rw * a.stride - a.pad;
             pb[j] = n * GH * GW;
@@ -206,6 +250,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     bool more = next();
+    // a tile no tap reaches (odd-parity tiles of a strided 1x1 data gradient) adds nothing: leave dx untouched
+    if (DGRAD && a.accumulate && !more) return;
     if (more) gload();
     while (more) {
         if constexpr (BD) bload();
@@ -276,9 +322,11 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = m0 + wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int lr = wm * (BM / 2) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + lr;
                 if (cok && row < a.M) {
-                    float* o = &a.y[(size_t)row * a.ldy + col];
+                    const int pix = (DGRAD && par) ? rowpix[DGRAD ? lr : 0] : row;
+                    float* o = &a.y[(size_t)pix * a.ldy + col];
                     *o = (DGRAD && a.accumulate) ? *o + acc[mb][nb][r] : acc[mb][nb][r] + bv;
                 }
             }
@@ -359,6 +407,12 @@ bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn) {
 
 // packed-weight ("B direct") launchers: a.w = k_pack_weights_x6 output.  Tiles: 128x64 or 64x64.
 bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm) {
+    static int parity = -1;
+    if (parity < 0) {
+        const char* e = getenv("ISWM_X6_PARITY");
+        parity = (e && e[0] == '0') ? 0 : 1;
+    }
+    a.nsplit = parity ? 0 : 1;
     const int nc = dgrad ? a.Cin : a.Cout;
     a.MT = (a.M + bm - 1) / bm;
     a.NT = (nc + 63) / 64;

@@ -64,8 +64,10 @@ class Bottleneck(_hip.HipModule):
         d2, dres = _hip.cba_bwd(self.conv3, self.bn3, c3, dout, sink)
         d1, _ = _hip.cba_bwd(self.conv2, self.bn2, c2, d2, sink)
         if cd is not None:
-            dx, _ = _hip.cba_bwd(self.downsample[0], self.downsample[1], cd, dres, sink)
-            dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink, dx=dx, accumulate=True)
+            # conv1 (1x1, stride 1) writes every input pixel; the strided downsample conv then only touches the
+            # pixels it reaches (its data gradient skips the other parity classes when accumulating)
+            dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink)
+            dx, _ = _hip.cba_bwd(self.downsample[0], self.downsample[1], cd, dres, sink, dx=dx, accumulate=True)
         else:
             # identity branch: the residual gradient IS dx; conv1's dgrad accumulates into it
             dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink, dx=dres, accumulate=True)
