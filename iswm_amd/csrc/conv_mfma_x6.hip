@@ -83,16 +83,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
         mt = k * qn + (k < rem ? k : rem) + idx;
     }
     const int m0 = mt * BM, n0 = nt * BN;
-#if defined(ISWM_X6_V1)
-    const int q = t & 7, idx_ = t >> 3;
-    const int r0 = (idx_ & ~7) | ((idx_ & 1) << 2) | ((idx_ >> 1) & 3);
-#else
     const int q = t & 7, r0 = t >> 3;
-#endif
-#if defined(ISWM_X6_STAGGER)
-    // experiment: offset the phase of co-resident workgroups so one splits/stages while the other multiplies
-    if ((blockIdx.x >> ISWM_X6_STAGGER) & 1) __builtin_amdgcn_s_sleep(24);
-#endif
 
     // row -> pixel of the tensor the rows live in (fwd: output Ho x Wo; dgrad: input H x W)
     const int RH = DGRAD ? a.H : a.Ho, RW = DGRAD ? a.W : a.Wo;
@@ -187,7 +178,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
     };
 
     float4 ra[AR], rb[BR];
-    auto gload = [&]() {
+    auto gload = [&](float4 (&ra)[AR]) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             ra[j] = ldg4(aptr[j]);
@@ -202,8 +193,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
         }
     };
     uint4 bfr[2][NB][3];   // BD: [k half][column block][plane]
-    auto bload = [&]() {   // fragments of the CURRENT chunk (tap, cc)
-        const uint4* p = wpk + (size_t)((tap * nCC + cc) * 2) * 192;
+    auto bload = [&](int k16) {   // fragments of the chunk whose first k16 block is k16 = (tap * nCC + cc) * 2
+        const uint4* p = wpk + (size_t)k16 * 192;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -211,15 +202,11 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bfr[ks][nb][pl] = p[nb * wpk_nb + (ks * 3 + pl) * 64];
     };
-    auto lstore = [&]() {   // split into bf16 planes and write 8 B per plane per row
+    auto lstore = [&](const float4 (&ra)[AR]) {   // split into bf16 planes and write 8 B per plane per row
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             uint2 h, m, l;
-#if defined(ISWM_X6_FAKE) && ISWM_X6_FAKE >= 2
-            h = make_uint2(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y)); m = h; l = h;   // timing experiment only
-#else
             split3(ra[j], h, m, l);
-#endif
             unsigned char* p = As + (r0 + 32 * j) * X6_PITCH + q * 8;
             *reinterpret_cast<uint2*>(p) = h;
             *reinterpret_cast<uint2*>(p + PLANE_A) = m;
@@ -229,11 +216,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             uint2 h, m, l;
-#if defined(ISWM_X6_FAKE) && ISWM_X6_FAKE >= 1
-            h = make_uint2(__float_as_uint(rb[j].x), __float_as_uint(rb[j].y)); m = h; l = h;   // timing experiment only
-#else
             split3(rb[j], h, m, l);
-#endif
             unsigned char* p = Bs + (r0 + 32 * j) * X6_PITCH + q * 8;
             *reinterpret_cast<uint2*>(p) = h;
             *reinterpret_cast<uint2*>(p + PLANE_B) = m;
@@ -249,16 +232,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    bool more = next();
-    // a tile no tap reaches (odd-parity tiles of a strided 1x1 data gradient) adds nothing: leave dx untouched
-    if (DGRAD && a.accumulate && !more) return;
-    if (more) gload();
-    while (more) {
-        if constexpr (BD) bload();
-        lstore();
-        __syncthreads();
-        const bool more2 = next();
-        if (more2) gload();
+    auto mfma_phase = [&]() {
         // fragment base: row (wave tile row + lane&31), k offset 8*(lane>>5) elements = 16 B
         const unsigned char* Ab = As + (wm * (BM / 2) + li) * X6_PITCH + lh * 16;
         const unsigned char* Bb = Bs + (wn * (BN / 2) + li) * X6_PITCH + lh * 16;
@@ -285,14 +259,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
                     bl[nb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_B);
                 }
             }
-#if defined(ISWM_X6_V3)
-#define X6_PROD(A_, B_)                                                          \
-    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                            \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                        \
-            acc[mb][nb] = mfma_bf16(A_[mb], B_[nb], acc[mb][nb]);
-            X6_PROD(al, bh) X6_PROD(ah, bl) X6_PROD(am, bm) X6_PROD(am, bh) X6_PROD(ah, bm) X6_PROD(ah, bh)
-#undef X6_PROD
-#else
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -306,10 +272,25 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
                     c = mfma_bf16(ah[mb], bh[nb], c);
                     acc[mb][nb] = c;
                 }
-#endif
         }
-        __syncthreads();
-        more = more2;
+    };
+    {
+        bool more = next();
+        // a tile no tap reaches (odd-parity tiles of a strided 1x1 data gradient) adds nothing: leave dx untouched
+        if (DGRAD && a.accumulate && !more) return;
+        if (more) gload(ra);
+        while (more) {
+            // B fragments of this chunk straight from L2 (issued before the split so they land behind it); fetching
+            // them a chunk ahead or keeping two activation chunks in flight measured no faster
+            if constexpr (BD) bload((tap * nCC + cc) * 2);
+            lstore(ra);
+            __syncthreads();
+            const bool more2 = next();
+            if (more2) gload(ra);
+            mfma_phase();
+            __syncthreads();
+            more = more2;
+        }
     }
 
     // ---- epilogue: identical C/D map to the fp32 kernels
