@@ -145,3 +145,44 @@ def test_ddp_bucketed_allreduce_gloo_world2():
         assert p.exitcode == 0
     assert res[0][1] and res[1][1]
     assert torch.equal(res[0][2], res[1][2])          # rank-0 parameters were broadcast
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """every entry point validates on the host before any launch: status 1 + a message, never a crash
+    (null pointers / bad geometry never reach the device)"""
+    import ctypes
+    from iswm_amd import _lib
+    lib = _lib.load()
+    err = lambda: lib.iswm_last_error().decode()
+    d = _lib.ConvDesc(2, 17, 17, 64, 17, 17, 64, 3, 3, 1, 1, 1, 64, 64)
+    assert lib.iswm_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None) == 1 and "null" in err()
+    assert lib.iswm_conv2d_fwd_packed(ctypes.byref(d), None, None, None, None, None, None) == 1 and "null" in err()
+    assert lib.iswm_conv2d_dgrad_packed(ctypes.byref(d), None, None, None, 0, None) == 1
+    assert lib.iswm_conv2d_pack_weights(ctypes.byref(d), 7, None, None, None) == 1 and "kind" in err()
+    bad = _lib.ConvDesc(2, 17, 17, 64, 9, 9, 64, 3, 3, 1, 1, 1, 64, 64)          # Ho/Wo inconsistent with the geometry
+    assert lib.iswm_conv2d_fwd(ctypes.byref(bad), None, None, None, None, None, None) == 1
+    dw = _lib.ConvDesc(2, 17, 17, 64, 17, 17, 32, 3, 3, 1, 1, 1, 64, 64)         # depthwise needs Cin == Cout
+    assert lib.iswm_dwconv2d_fwd(ctypes.byref(dw), None, None, 64, None, None, None) == 1 and "depthwise" in err()
+    assert lib.iswm_confusion_matrix(None, 0, None, 1, 10, 2, None, None) == 1
+    buf = (ctypes.c_longlong * 4)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.iswm_confusion_matrix(p, 0, p, 1, 10, 99, p, None) == 1 and "n_classes" in err()
+    assert lib.iswm_confusion_matrix(p, 3, p, 1, 10, 2, p, None) == 1 and "dtype" in err()
+    assert lib.iswm_augment_batch(None, None, None, None, 1, 8, 8, None, None, None, None, None) == 1
+    assert lib.iswm_set_conv_math(5) == 1
+    # packed-weight sizes are pure host arithmetic: [ceil(N/64)*2 column blocks][K/16][3 planes][64 lanes] x 16 B
+    old = lib.iswm_get_conv_math()
+    try:
+        lib.iswm_set_conv_math(1)
+        assert lib.iswm_conv2d_packed_weight_bytes(ctypes.byref(d), 0) == 2 * (9 * 64 // 16) * 3 * 64 * 16
+        d48 = _lib.ConvDesc(2, 17, 17, 256, 17, 17, 48, 1, 1, 1, 0, 1, 256, 48)
+        assert lib.iswm_conv2d_packed_weight_bytes(ctypes.byref(d48), 0) == 2 * (256 // 16) * 3 * 64 * 16
+        assert lib.iswm_conv2d_packed_weight_bytes(ctypes.byref(d48), 1) == 0      # Cout = 48 is not 32-aligned
+        tiles, rows = ctypes.c_int(0), ctypes.c_int(0)
+        big = _lib.ConvDesc(16, 33, 33, 256, 33, 33, 256, 3, 3, 1, 1, 1, 256, 256)
+        assert lib.iswm_conv2d_fwd_packed_stat_layout(ctypes.byref(big), ctypes.byref(tiles), ctypes.byref(rows)) == 0
+        assert (tiles.value, rows.value) == (16 * 9, 0)                             # 11 x 11 patches, per-tile counts
+        lib.iswm_set_conv_math(0)
+        assert lib.iswm_conv2d_packed_weight_bytes(ctypes.byref(d), 0) == 0         # exact-fp32 path: no packed form
+    finally:
+        lib.iswm_set_conv_math(old)
