@@ -400,7 +400,7 @@ def test_baseline_large_tile_configs(os_, size):
             loss.backward()
             g = m.backbone.layer3[0].conv2.weight.grad
             assert bool(torch.isfinite(g).all())
-            res.append((float(loss), lg.detach().clone(), g.clone()))
+            res.append((float(loss.detach()), lg.detach().clone(), g.clone()))
         finally:
             lib.iswm_set_conv_math(old)
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])     # bit-identical repeat
@@ -479,3 +479,33 @@ def test_converted_head_trains():
         assert all(bool(torch.isfinite(g).all()) for g in gs) and all(float(g.abs().max()) > 0 for g in gs)
         outs.append((lg.detach().clone(), gs))
     assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+def test_baseline_config0_plumbing_size():
+    """BASELINE.json configs[0] geometry -- 256x256 two-class tiles, batch 2 (the reference has no mobilenet, SURVEY
+    F1, so resnet50 as SURVEY 8d prescribes): eval logits and the training loss vs the CPU oracle on the same
+    weights, argmax bit-exact away from near-ties."""
+    from iswm_amd import ops
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle import loss as oloss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.synth import synth_images, synth_labels
+    m, cfg, sd = _build("resnet50", 16)
+    x = synth_images(2, 256, 256, seed=41)
+    lab = synth_labels(2, 256, 256, seed=41)
+    m.eval()
+    with torch.no_grad():
+        lg = m(x.to(dev()))
+        lo = OracleDeepLab(cfg, sd, dropout_p=0.0).eval()(x)
+    assert lg.shape == (2, 2, 256, 256) and rel_err(lg, lo) <= RTOL
+    margin = (lo[:, 1] - lo[:, 0]).abs()
+    sure = margin > 2 * RTOL * lo.abs().max()
+    assert float(sure.float().mean()) > 0.95
+    assert torch.equal(ops.argmax_nchw(lg).cpu()[sure], lo.max(1)[1][sure])
+    m.train()
+    lg = m(x.to(dev()))
+    with torch.no_grad():
+        lt = OracleDeepLab(cfg, sd, dropout_p=0.0).train()(x)
+    w = torch.tensor([1.0, 3.0])
+    assert rel_err(lg, lt) <= RTOL
+    assert rel_err(CrossEntropyLoss(weight=w)(lg, lab.to(dev())), oloss.weighted_ce(lt, lab, w)) <= RTOL
