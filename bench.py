@@ -258,9 +258,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "deeplabv3plus_%s output_stride=%d, %dx%d synthetic tiles, %d images/GPU "
-                            "(BASELINE.json configs[2]: global batch 128 over 8 GPUs), weighted CE [1,3], "
+                            "(%s), weighted CE [1,3], "
                             "SGD-nesterov + cosine LR; fp32 tensors, conv products via %s" %
                             (args.model, args.output_stride, S, S, B,
+                             "BASELINE.json configs[2]: global batch 128 over 8 GPUs" if args.model == "resnet101"
+                             else "BASELINE.json configs[1]",
                              "six bf16 MFMAs on an exact 3-way operand split (bf16x6, fp32-level error)"
                              if math_name == "bf16x6" else "v_mfma_f32_32x32x2_f32"),
                 "conv_math": math_name,
