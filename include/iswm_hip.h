@@ -88,6 +88,19 @@ int iswm_conv2d_dgrad_wt(const iswm_conv_desc* d, const float* dy, const float* 
  * count -- Cin forward, Cout data gradient -- is not a multiple of 32). */
 size_t iswm_conv2d_packed_weight_bytes(const iswm_conv_desc* d, int kind);
 int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed, iswm_stream_t stream);
+/* Batched form: all conv weights of a model in ONE launch (a step otherwise issues two tiny pack kernels per conv).
+ * jobs_dev is a DEVICE array sorted by first_block; job i owns workgroups [first_block, first_block +
+ * iswm_pack_job_blocks(...)); total_blocks is the sum.  iswm_packed_weight_bytes is the buffer size for
+ * (Cout, taps, Cin, kind), 0 if the gathered channel count (Cin forward, Cout data gradient) is not 32-aligned. */
+typedef struct iswm_pack_job {
+    const float* w;         /* [Cout][taps][Cin] (OHWI) */
+    void* packed;
+    int Cout, taps, Cin, kind;
+    int first_block, reserved;
+} iswm_pack_job;
+size_t iswm_packed_weight_bytes(int Cout, int taps, int Cin, int kind);
+int iswm_pack_job_blocks(int Cout, int taps, int Cin, int kind);
+int iswm_pack_weights_batch(const iswm_pack_job* jobs_dev, int njobs, int total_blocks, iswm_stream_t stream);
 /* layout of the BN partials iswm_conv2d_fwd_packed writes: tiles x Cout floats per plane (sum, centred M2).
  * *tile_rows > 0: every tile holds that many rows (the last one the remainder); *tile_rows == 0: the tiles are
  * image patches of varying size and their row counts follow the planes as floats (partials + 2*tiles*Cout), so

@@ -35,6 +35,9 @@ _SIGS = {
     "iswm_conv2d_dgrad_wt": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
     "iswm_conv2d_packed_weight_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "iswm_conv2d_pack_weights": (c_int, [POINTER(ConvDesc), c_int, P, P, P]),
+    "iswm_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "iswm_pack_job_blocks": (c_int, [c_int, c_int, c_int, c_int]),
+    "iswm_pack_weights_batch": (c_int, [P, c_int, c_int, P]),
     "iswm_conv2d_fwd_packed_stat_layout": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
     "iswm_conv2d_fwd_packed": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "iswm_conv2d_dgrad_packed": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),

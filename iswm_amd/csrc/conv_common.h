@@ -65,6 +65,8 @@ bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn);
 bool launch_conv_dgrad_x6(ConvArgs a, hipStream_t s, int bm, int bn);
 bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm);
 size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad);
+void launch_pack_weights_batch(const void* jobs_dev, int njobs, int total_blocks, hipStream_t s);
+int pack_job_blocks_x6(int Cout, int T, int Cin, bool dgrad);
 void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, hipStream_t s);
 void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s);
 

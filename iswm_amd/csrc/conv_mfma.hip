@@ -964,6 +964,25 @@ extern "C" int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const
     return check_launch("pack_weights");
 }
 
+/* ---- batched packing: every conv of a model in one launch ---- */
+extern "C" size_t iswm_packed_weight_bytes(int Cout, int taps, int Cin, int kind) {
+    if (Cout <= 0 || taps <= 0 || Cin <= 0 || (kind != 0 && kind != 1) || (kind ? Cout : Cin) % 32 != 0) return 0;
+    return packed_weight_bytes_x6(Cout, taps, Cin, kind == 1);
+}
+
+extern "C" int iswm_pack_job_blocks(int Cout, int taps, int Cin, int kind) {
+    if (iswm_packed_weight_bytes(Cout, taps, Cin, kind) == 0) return 0;
+    return pack_job_blocks_x6(Cout, taps, Cin, kind == 1);
+}
+
+extern "C" int iswm_pack_weights_batch(const iswm_pack_job* jobs_dev, int njobs, int total_blocks,
+                                       iswm_stream_t stream) {
+    ISWM_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_weights_batch: bad argument");
+    static_assert(sizeof(iswm_pack_job) == 40, "iswm_pack_job layout");
+    launch_pack_weights_batch(jobs_dev, njobs, total_blocks, (hipStream_t)stream);
+    return check_launch("pack_weights_batch");
+}
+
 extern "C" int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, const void* wpk, const float* bias,
                                       float* y, float* stat_partials, iswm_stream_t stream) {
     if (int e = validate(d)) return e;

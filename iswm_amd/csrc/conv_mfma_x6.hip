@@ -414,10 +414,8 @@ bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm) {
 // packed[((cb * K16 + k16) * 3 + plane) * 64 + lane] (uint4) holds, for column cb*32 + (lane & 31), the 8 bf16 of
 // plane {hi, mid, lo} at k = k16*16 + 8*(lane >> 5) .. +7.  Columns >= NC are zero; cb runs to ceil(NC/64)*2.
 template <bool DGRAD>
-__global__ __launch_bounds__(256) void k_pack_weights_x6(const float* __restrict__ w, uint4* __restrict__ packed,
-                                                         int Cout, int T, int Cin, int K16, int total) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+__device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int T,
+                                                  int Cin, int K16, int idx) {
     const int lane = idx & 63, f = idx >> 6;
     const int k16 = f % K16, cb = f / K16;
     const int col = cb * 32 + (lane & 31), k0 = k16 * 16 + 8 * (lane >> 5);
@@ -437,6 +435,50 @@ __global__ __launch_bounds__(256) void k_pack_weights_x6(const float* __restrict
     o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
     o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
     o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void k_pack_weights_x6(const float* __restrict__ w, uint4* __restrict__ packed,
+                                                         int Cout, int T, int Cin, int K16, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    pack_weights_body<DGRAD>(w, packed, Cout, T, Cin, K16, idx);
+}
+
+// All conv weights of a model in ONE launch (a training step otherwise issues ~220 tiny pack kernels, each mostly
+// launch latency): jobs[] is sorted by first_block; a workgroup finds its job by binary search.
+struct PackJob {             // mirrors iswm_pack_job
+    const float* w;
+    void* packed;
+    int Cout, T, Cin, kind;
+    int first_block, reserved;
+};
+
+__global__ __launch_bounds__(256) void k_pack_weights_batch(const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                       // last job with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int NC = j.kind ? j.Cin : j.Cout, GC = j.kind ? j.Cout : j.Cin;
+    const int cbs = ((NC + 63) / 64) * 2, K16 = j.T * GC / 16;
+    const int idx = (b - j.first_block) * 256 + threadIdx.x;
+    if (idx >= cbs * K16 * 64) return;
+    if (j.kind) pack_weights_body<true>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);
+    else pack_weights_body<false>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);
+}
+
+void launch_pack_weights_batch(const void* jobs_dev, int njobs, int total_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_weights_batch, dim3(total_blocks), dim3(256), 0, s, (const PackJob*)jobs_dev, njobs);
+}
+
+int pack_job_blocks_x6(int Cout, int T, int Cin, bool dgrad) {
+    const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
+    const long long total = (long long)((NC + 63) / 64) * 2 * (T * GC / 16) * 64;
+    return (int)((total + 255) / 256);
 }
 
 size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad) {

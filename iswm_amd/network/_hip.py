@@ -13,6 +13,8 @@ and the whole model is ONE node in torch's autograd graph (``_Bridge``), so
 ``loss.backward()`` / ``optimizer.step()`` in train.py work unchanged while no
 torch op ever touches an activation.  All compute is libiswm_hip.so kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -168,6 +170,16 @@ class Conv2d(HipModule, nn.Conv2d):
         wp[:self.out_channels, :, :, :self.in_channels] = v
         return wp
 
+    def packed(self, kind):
+        """this weight pre-packed for the bf16x6 forward (0) / data-gradient (1) kernel by the model's WeightPacker,
+        or None (the kernel wrappers then pack it themselves).  Valid only inside the forward/backward window it was
+        made for and only while the parameter is untouched."""
+        e = getattr(self, "_iswm_wpk", None)
+        if e is None or not e["live"] or e["epoch"] != ops.WEIGHTS_EPOCH or e["version"] != self.weight._version or \
+                e["ptr"] != self.weight.data_ptr():
+            return None
+        return e["buf"][kind]
+
     def bias_p(self):
         if self.bias is None:
             return None
@@ -202,7 +214,7 @@ class Conv2d(HipModule, nn.Conv2d):
     # -- standalone conv (+bias), e.g. the final 1x1 classifier ---------------------------
     def fwd(self, x, save, out=None):
         g = self.geometry(x)
-        y, _, _ = ops.conv2d_fwd(x, self.ohwi(), g, bias=self.bias_p(), out=out)
+        y, _, _ = ops.conv2d_fwd(x, self.ohwi(), g, bias=self.bias_p(), out=out, wpk=self.packed(0))
         self._saved = (x, g) if save else None
         return y
 
@@ -215,7 +227,7 @@ class Conv2d(HipModule, nn.Conv2d):
         self.write_wgrad(x, dy, g, sink)
         if not need_dx:
             return None
-        return ops.conv2d_dgrad(dy, self.ohwi(), g, tuple(x.shape), dx, accumulate)
+        return ops.conv2d_dgrad(dy, self.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=self.packed(1))
 
     def out_channels_of(self, cin):
         return self.out_channels
@@ -316,7 +328,7 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise NotImplementedError("HIP BatchNorm2d supports affine=True, momentum!=None, running stats")
     if conv.bias is None:
-        y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training)
+        y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training, wpk=conv.packed(0))
     else:
         # a biased conv in front of a BatchNorm (only reachable through convert_to_separable_conv on a biased
         # conv): the fused epilogue statistics do not include the bias, so take them in a separate column pass
@@ -366,10 +378,10 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
         sink.target(conv.bias).copy_(ops.colsum(dy)[:conv.out_channels])
         sink.done(conv.bias)
     if sep is not None:
-        dmid = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape))
+        dmid = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), wpk=conv.packed(1))
         return sep.body[0].bwd(dmid, sink, need_dx, dx, accumulate), dres
     if need_dx:
-        dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate)
+        dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=conv.packed(1))
     else:
         dx = None
     return dx, dres
@@ -387,6 +399,75 @@ def fuse_batch_counters(root):
         m._buffers["num_batches_tracked"] = flat[i]
         m._iswm_nbt_fused = True
     return flat
+
+
+_BATCH_PACK = os.environ.get("ISWM_BATCH_PACK", "1") != "0"     # 0: every conv call packs its own weight (tuning switch)
+
+
+class WeightPacker(object):
+    """Packs the weights of every (unpadded) Conv2d under `root` for the bf16x6 kernels in ONE launch per forward
+    pass -- the exact 3-way split in MFMA fragment order, csrc/conv_mfma_x6.hip k_pack_weights_batch -- instead of
+    two tiny launches per conv per step.  Buffers and the device job table persist; they are rebuilt when a
+    parameter moved.  `begin()` at the start of a model forward makes the buffers live, `end()` retires them."""
+
+    def __init__(self, root):
+        self.convs = [m for m in root.modules() if isinstance(m, Conv2d) and not m.needs_pack()]
+        self.key, self.jobs, self.njobs, self.blocks, self.entries = None, None, 0, 0, []
+
+    def _build(self, dev):
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        jobs, entries, first = [], [], 0
+        keep = []
+        for m in self.convs:
+            w = m.weight
+            v = w.permute(0, 2, 3, 1)
+            if not (w.is_cuda and v.is_contiguous()):
+                continue
+            taps = m.kernel_size[0] * m.kernel_size[1]
+            bufs = {}
+            for kind in (0, 1):
+                nb = lib.iswm_packed_weight_bytes(m.out_channels, taps, m.in_channels, kind)
+                if nb == 0:
+                    continue
+                buf = torch.empty((nb // 4,), dtype=torch.float32, device=dev)
+                bufs[kind] = buf
+                jobs.append((w.data_ptr(), buf.data_ptr(), m.out_channels, taps, m.in_channels, kind, first, 0))
+                first += lib.iswm_pack_job_blocks(m.out_channels, taps, m.in_channels, kind)
+            if bufs:
+                e = dict(live=False, epoch=-1, version=-1, ptr=w.data_ptr(), buf={0: bufs.get(0), 1: bufs.get(1)})
+                m._iswm_wpk = e
+                entries.append((m, e))
+                keep.append(bufs)
+
+        class _Job(ctypes.Structure):
+            _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("Cout", ctypes.c_int), ("taps", ctypes.c_int),
+                        ("Cin", ctypes.c_int), ("kind", ctypes.c_int), ("first_block", ctypes.c_int),
+                        ("reserved", ctypes.c_int)]
+        arr = (_Job * max(1, len(jobs)))()
+        for i, j in enumerate(jobs):
+            arr[i] = _Job(*j)
+        self.jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev) if jobs else None
+        self.njobs, self.blocks, self.entries = len(jobs), first, entries
+
+    def begin(self):
+        from .. import _lib
+        if _lib.load().iswm_get_conv_math() != 1 or not ops._USE_PACKED or not self.convs or not _BATCH_PACK:
+            return
+        key = tuple(m.weight.data_ptr() for m in self.convs)
+        if key != self.key:
+            self._build(self.convs[0].weight.device)
+            self.key = key
+        if self.njobs == 0:
+            return
+        ops.call("iswm_pack_weights_batch", ops._p(self.jobs), self.njobs, self.blocks, ops._stream())
+        for m, e in self.entries:
+            e["live"], e["epoch"], e["version"] = True, ops.WEIGHTS_EPOCH, m.weight._version
+
+    def end(self):
+        for _, e in self.entries:
+            e["live"] = False
 
 
 class SeparableBase(HipModule):

@@ -51,15 +51,30 @@ class _SimpleSegmentationModel(nn.Module):
             object.__setattr__(self, "_iswm_nbt", flat)
         return flat
 
+    def _packer(self):
+        pk = getattr(self, "_iswm_packer", None)
+        if pk is None:
+            pk = _hip.WeightPacker(self)
+            object.__setattr__(self, "_iswm_packer", pk)
+        return pk
+
     def _fwd(self, x, save):
         n, c, h, w = x.shape
         if self.training:
             flat = self._counters()
             if flat is not None:
                 flat.add_(1)
-        xh = ops.nchw_to_nhwc(x)                               # pads 3 -> 4 channels
-        feats = self.backbone.fwd(xh, save)
-        yl = self.classifier.fwd(feats, save)                  # [B, hl, wl, pad4(num_classes)]
+        pk = self._packer()
+        pk.begin()                                             # all conv weights -> bf16x6 fragments, one launch
+        try:
+            xh = ops.nchw_to_nhwc(x)                           # pads 3 -> 4 channels
+            feats = self.backbone.fwd(xh, save)
+            yl = self.classifier.fwd(feats, save)              # [B, hl, wl, pad4(num_classes)]
+        except BaseException:
+            pk.end()
+            raise
+        if not save:
+            pk.end()                                           # no backward will follow: retire the packed weights
         nc = self.classifier.num_classes
         self._saved = (tuple(yl.shape), c) if save else None
         # bilinear upsample to the input size fused with NHWC -> NCHW (reference :22)
@@ -69,11 +84,14 @@ class _SimpleSegmentationModel(nn.Module):
         (n, hl, wl, cp), cin = self._saved
         self._saved = None
         sink = _hip.GradSink(self._iswm_on_ready)
-        dyl = ops.bilinear_to_nchw_bwd(dlogits, hl, wl, cp)
-        dfeats = self.classifier.bwd(dyl, sink)
-        if getattr(self, "_debug_keep_dfeats", False):
-            self._debug_dfeats = {k: v.clone() for k, v in dfeats.items()}
-        dxh = self.backbone.bwd(dfeats, sink, need_dx)
+        try:
+            dyl = ops.bilinear_to_nchw_bwd(dlogits, hl, wl, cp)
+            dfeats = self.classifier.bwd(dyl, sink)
+            if getattr(self, "_debug_keep_dfeats", False):
+                self._debug_dfeats = {k: v.clone() for k, v in dfeats.items()}
+            dxh = self.backbone.bwd(dfeats, sink, need_dx)
+        finally:
+            self._packer().end()
         return ops.nhwc_to_nchw(dxh, cin) if need_dx else None
 
     def forward(self, x):

@@ -199,8 +199,17 @@ def _check_w(w_ohwi, g):
                          ((g.cout, g.kh, g.kw, g.cin), tuple(w_ohwi.shape), w_ohwi.stride()))
 
 
-def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
-    """y = conv(x, w) [+ bias]; returns (y, partials|None, (tiles, tile_rows))."""
+WEIGHTS_EPOCH = 0     # bumped by the fused optimizers: packed-weight buffers made before a step are stale after it
+
+
+def weights_changed():
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
+def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False, wpk=None):
+    """y = conv(x, w) [+ bias]; returns (y, partials|None, (tiles, tile_rows)).  wpk: this weight already packed
+    for the forward kernel (network._hip.WeightPacker), else it is packed here."""
     ldx = geom(x)[4]
     _check_w(w_ohwi, g)
     if out is None:
@@ -221,8 +230,9 @@ def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False):
             tiles = (nt.value, tr.value)
             flat = torch.empty((2 * nt.value * g.cout + nt.value,), dtype=torch.float32, device=x.device)
             partials = flat[:2 * nt.value * g.cout].view(2, nt.value, g.cout)   # per-tile row counts follow
-        wpk = torch.empty((nb // 4,), dtype=torch.float32, device=x.device)
-        call("iswm_conv2d_pack_weights", ctypes.byref(d), 0, _p(w_ohwi), _p(wpk), _stream())
+        if wpk is None:
+            wpk = torch.empty((nb // 4,), dtype=torch.float32, device=x.device)
+            call("iswm_conv2d_pack_weights", ctypes.byref(d), 0, _p(w_ohwi), _p(wpk), _stream())
         with _timed(d, 3, g):
             call("iswm_conv2d_fwd_packed", ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(out), _p(partials), _stream())
         return out, partials, tiles
@@ -238,8 +248,9 @@ def _packed_bytes(d, kind):
     return _lib.load().iswm_conv2d_packed_weight_bytes(ctypes.byref(d), kind) if _USE_PACKED else 0
 
 
-def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
-    """dx (=|+=) conv^T(dy, w).  x_like_shape = (N,H,W,Cin) of the conv input."""
+def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=None):
+    """dx (=|+=) conv^T(dy, w).  x_like_shape = (N,H,W,Cin) of the conv input.  wpk: weight already packed for the
+    data-gradient kernel."""
     ldy = geom(dy)[4]
     _check_w(w_ohwi, g)
     if dx is None:
@@ -249,8 +260,9 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False):
     d = g.desc(ldx, ldy)
     nb = _packed_bytes(d, 1)
     if nb:
-        wpk = torch.empty((nb // 4,), dtype=torch.float32, device=dy.device)
-        call("iswm_conv2d_pack_weights", ctypes.byref(d), 1, _p(w_ohwi), _p(wpk), _stream())
+        if wpk is None:
+            wpk = torch.empty((nb // 4,), dtype=torch.float32, device=dy.device)
+            call("iswm_conv2d_pack_weights", ctypes.byref(d), 1, _p(w_ohwi), _p(wpk), _stream())
         with _timed(d, 4, g):
             call("iswm_conv2d_dgrad_packed", ctypes.byref(d), _p(dy), _p(wpk), _p(dx), int(bool(accumulate)), _stream())
         return dx

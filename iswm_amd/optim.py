@@ -123,6 +123,7 @@ class FusedSGD(_FusedBase):
         self._push_hyper(g["lr"])
         ops.sgd_step(self.arena.data, self.arena.grad, self._buf, self._hyper_dev, g["momentum"],
                      g["weight_decay"], g["nesterov"])
+        ops.weights_changed()
         return loss
 
     def load_state_dict(self, state_dict):
@@ -160,6 +161,7 @@ class FusedAdam(_FusedBase):
         self._push_hyper(g["lr"], 1.0 - b1 ** self._t, 1.0 - b2 ** self._t)
         ops.adam_step(self.arena.data, self.arena.grad, self._m, self._v, self._hyper_dev, b1, b2, g["eps"],
                       g["weight_decay"], g["decoupled"])
+        ops.weights_changed()
         for p in self.arena.params:
             self.state[p]["step"] += 1
         return loss
