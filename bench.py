@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--output-stride", type=int, default=16, choices=[8, 16])
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=513)
+    ap.add_argument("--torch-baseline", action="store_true",
+                    help="also time the same step on stock PyTorch-ROCm ops (MIOpen) on this GPU (adds ~2 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--conv-math", default=None, choices=["f32", "bf16x6"],
@@ -128,6 +130,49 @@ def cpu_baseline(model_name, output_stride, size):
             "sample": "%d timed steps (1 warm-up) of oracle/ deeplabv3plus_%s os%d at %dx%d, batch %d, "
                       "fwd + weighted CE + bwd + SGD-nesterov, torch CPU fp32" %
                       (n, model_name, output_stride, size, size, b)}
+
+
+def torch_rocm_baseline(model_name, output_stride, size, batch, dev):
+    """The same training step as stock PyTorch-ROCm ops (MIOpen convolutions, ATen BatchNorm / loss / autograd) on THIS
+    GPU: oracle/ -- the torch restatement of the reference model -- moved to the device.  It is what the reference
+    code itself would run on an MI355X.  Optional (--torch-baseline): MIOpen's first-step kernel search takes ~1 min."""
+    import torch
+    from oracle import loss as oloss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.optim import OracleSGD
+    from oracle.synth import ArchCfg, synth_images, synth_labels, synth_state_dict
+    cfg = ArchCfg("deeplabv3plus", model_name, 2, output_stride)
+    sd = {k: v.to(dev) for k, v in synth_state_dict(cfg).items()}
+    o = OracleDeepLab(cfg, sd, dropout_p=0.1).train()
+    opt = OracleSGD(o.parameters())
+    x = synth_images(batch, size, size, seed=0).to(dev)
+    lab = synth_labels(batch, size, size, seed=0).to(dev)
+    w = torch.tensor([1.0, 3.0], device=dev)
+
+    def step():
+        loss = oloss.weighted_ce(o(x), lab, w)
+        o.zero_grad()
+        loss.backward()
+        opt.step()
+
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first = time.perf_counter() - t0
+    print("[bench] torch_rocm_baseline: first step (MIOpen search) %.1f s" % first, file=sys.stderr, flush=True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(batch / dt, 3), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
+            "first_step_s": round(first, 1),
+            "note": "identical step on stock torch %s ops (MIOpen convs, NCHW fp32) on the same GPU: oracle/ on cuda" %
+                    torch.__version__}
 
 
 def main():
@@ -316,6 +361,12 @@ def main():
             out["alt_conv_math_f32"] = {"value": round(B / dt1, 3), "unit": "images/sec",
                                         "ms_per_step": round(dt1 * 1e3, 3),
                                         "note": "identical step on v_mfma_f32_32x32x2_f32 kernels (ISWM_CONV_MATH=f32)"}
+        if world == 1 and args.torch_baseline:
+            del model, net, opt, images, labels          # free the product's activations / arenas first
+            torch.cuda.empty_cache()
+            tb = torch_rocm_baseline(args.model, args.output_stride, S, B, dev)
+            tb["speedup_of_this_path"] = round(out["value"] / tb["value"], 3)
+            out["torch_rocm_baseline"] = tb
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, args.output_stride, S)
         print(json.dumps(out), flush=True)
