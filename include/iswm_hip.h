@@ -157,10 +157,12 @@ int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const float* scale,
  *   ATen's CPU kernel does);
  *   dy = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M) (training) or gamma*invstd*dz (eval);
  *   dres (optional) = dz, the gradient of the identity branch.
- * workspace: iswm_bn_bwd_workspace(M, C) bytes, 16-byte aligned. */
+ * workspace: iswm_bn_bwd_workspace(M, C) bytes, 16-byte aligned.  * mask_scale / mask_shift (optional, ReLU without residual): the forward's scale and shift -- the ReLU sign pattern is
+ * then recomputed as (y - mean)*scale + shift > 0 (bit-identical to iswm_bn_apply) and `out` is not read. */
 size_t iswm_bn_bwd_workspace(int64_t M, int C);
 int iswm_bn_backward(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
                      int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                     const float* mask_scale, const float* mask_shift,
                      int relu, int training, float* dgamma, float* dbeta, float* dy, int lddy,
                      float* dres, int lddres, void* workspace, size_t workspace_bytes,
                      iswm_stream_t stream);

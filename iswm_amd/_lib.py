@@ -54,7 +54,7 @@ _SIGS = {
     "iswm_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P, P, P, P]),
     "iswm_bn_apply": (c_int, [P, c_int64, c_int, c_int, P, P, P, P, c_int, c_int, P, c_int, P]),
     "iswm_bn_bwd_workspace": (c_size_t, [c_int64, c_int]),
-    "iswm_bn_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P, P, c_int, c_int, P, P, P, c_int,
+    "iswm_bn_backward": (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P, P, P, P, P, c_int, c_int, P, P, P, c_int,
                                  P, c_int, P, c_size_t, P]),
     "iswm_colsum_finalize": (c_int, [P, c_int, c_int, P, P, P]),
     "iswm_maxpool3x3s2_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P]),

@@ -165,12 +165,17 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
 // (acc_type<float, false>), and over a handful of samples (the ASPP image-pooling branch
 // normalises over N x 1 x 1) dy = dz - mean(dz) - xhat*mean(dz*xhat) cancels to ~eps/(var+eps) of
 // its terms, so fp32 rounding of xhat would show up at the 1e-3 level.  The kernels stay HBM-bound.
-template <bool RELU, bool DBL>
+// RELU: 0 = no activation, 1 = ReLU mask read from the saved output (out > 0), 2 = ReLU mask RECOMPUTED from y with the
+// forward's own expression (y - mean) * scale + shift > 0 (bit-identical to k_bn_apply, which has no residual in this
+// case) -- the saved output is then never read: 8 instead of 12 bytes per element in this pass
+template <int RELU, bool DBL>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dout, int ldd,
                                                        const float* __restrict__ out, int ldo,
                                                        const float* __restrict__ y, int ldy, int64_t M,
                                                        int C4, int C, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, int CQ, int RL,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ mscale,
+                                                       const float* __restrict__ mshift, int CQ, int RL,
                                                        int tiles, double* __restrict__ partials) {
     __shared__ double red[2 * 256 * 4];
     RowThread rt = row_thread(C4, CQ, RL);
@@ -178,6 +183,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
     if (rt.active) {
         const int c = rt.c4 * 4;
         const float4 mu = ld4(mean + c), is = ld4(invstd + c);
+        float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
+        if (RELU == 2) {
+            msc = ld4(mscale + c);
+            msh = ld4(mshift + c);
+        }
         // fp32 partial sums over runs of 8 rows (4 loads x 3 tensors in flight per step), flushed into
         // double: keeps the double-accumulated result to ~1e-7 while staying load-bound, not DP-latency-bound
         for (int64_t r = rt.row0; r < M; r += 8 * rt.rstep) {
@@ -187,12 +197,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
                 const int64_t rr = r + u * rt.rstep;
                 if (rr < M) {
                     float4 g = ld4(dout + rr * ldd + c);
-                    if (RELU) {
+                    float4 v = ld4(y + rr * ldy + c);
+                    if (RELU == 1) {
                         float4 o = ld4(out + rr * ldo + c);
                         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
                         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+                    } else if (RELU == 2) {
+                        g.x = (v.x - mu.x) * msc.x + msh.x > 0.f ? g.x : 0.f;
+                        g.y = (v.y - mu.y) * msc.y + msh.y > 0.f ? g.y : 0.f;
+                        g.z = (v.z - mu.z) * msc.z + msh.z > 0.f ? g.z : 0.f;
+                        g.w = (v.w - mu.w) * msc.w + msh.w > 0.f ? g.w : 0.f;
                     }
-                    float4 v = ld4(y + rr * ldy + c);
                     if (DBL) {   // few rows per channel (image-pooling branch): everything in double
                         const double gd[4] = {g.x, g.y, g.z, g.w}, vd[4] = {v.x, v.y, v.z, v.w};
                         const double mud[4] = {mu.x, mu.y, mu.z, mu.w}, isd[4] = {is.x, is.y, is.z, is.w};
@@ -270,13 +285,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const T* __restrict__ p
 }
 
 // ---- backward stage 2 ---------------------------------------------------------------------------
-template <bool RELU, bool TRAIN, bool DRES>
+template <int RELU, bool TRAIN, bool DRES>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dout, int ldd,
                                                       const float* __restrict__ out, int ldo,
                                                       const float* __restrict__ y, int ldy, int64_t M,
                                                       int C4, int C, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma,
+                                                      const float* __restrict__ mscale,
+                                                      const float* __restrict__ mshift,
                                                       const double* __restrict__ sums, double inv_count,
                                                       float* __restrict__ dy, int lddy,
                                                       float* __restrict__ dres, int lddres, int CQ, int RL) {
@@ -287,6 +304,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const float4 ga = gamma ? ld4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
     const double mud[4] = {mu.x, mu.y, mu.z, mu.w}, isd[4] = {is.x, is.y, is.z, is.w};
     const double gi[4] = {(double)ga.x * is.x, (double)ga.y * is.y, (double)ga.z * is.z, (double)ga.w * is.w};
+    float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;
+    if (RELU == 2) {
+        msc = ld4(mscale + c);
+        msh = ld4(mshift + c);
+    }
     double k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
     if (TRAIN) {
 #pragma unroll
@@ -297,16 +319,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     }
     for (int64_t r = rt.row0; r < M; r += rt.rstep) {
         float4 g = ld4(dout + r * ldd + c);
-        if (RELU) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TRAIN || RELU == 2) v = ld4(y + r * ldy + c);
+        if (RELU == 1) {
             float4 o = ld4(out + r * ldo + c);
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        } else if (RELU == 2) {
+            g.x = (v.x - mu.x) * msc.x + msh.x > 0.f ? g.x : 0.f;
+            g.y = (v.y - mu.y) * msc.y + msh.y > 0.f ? g.y : 0.f;
+            g.z = (v.z - mu.z) * msc.z + msh.z > 0.f ? g.z : 0.f;
+            g.w = (v.w - mu.w) * msc.w + msh.w > 0.f ? g.w : 0.f;
         }
         if (DRES) st4(dres + r * lddres + c, g);
         const double gd[4] = {g.x, g.y, g.z, g.w};
         float d[4];
         if (TRAIN) {
-            float4 v = ld4(y + r * ldy + c);
             const double vd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -411,11 +439,14 @@ extern "C" size_t iswm_bn_bwd_workspace(int64_t M, int C) {
 
 extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, int ldo, const float* y, int ldy,
                                 int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                                const float* mask_scale, const float* mask_shift,
                                 int relu, int training, float* dgamma, float* dbeta, float* dy, int lddy,
                                 float* dres, int lddres, void* workspace, size_t workspace_bytes,
                                 iswm_stream_t stream) {
     if (int e = chk_rows("bn_backward", M, C, ldy)) return e;
-    ISWM_REQUIRE(dout && y && mean && invstd && dgamma && dbeta && dy && workspace && (!relu || out),
+    // ReLU without a residual: the sign pattern is recomputed from y when the forward's scale / shift are given
+    const bool masky = relu && !dres && mask_scale && mask_shift;
+    ISWM_REQUIRE(dout && y && mean && invstd && dgamma && dbeta && dy && workspace && (!relu || out || masky),
                  "bn_backward: null pointer");
     ISWM_REQUIRE(ldd % 4 == 0 && ldd >= C && lddy % 4 == 0 && lddy >= C && (!relu || (ldo % 4 == 0 && ldo >= C)) &&
                      (!dres || (lddres % 4 == 0 && lddres >= C)),
@@ -431,12 +462,14 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
         dim3 grid(p.rowblocks, p.colblocks), blk(256);
 #define RLAUNCH(R, D)                                                                                           \
     hipLaunchKernelGGL((k_bn_bwd_reduce<R, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean, invstd, \
-                       p.CQ, p.RL, tiles, partials)
+                       mask_scale, mask_shift, p.CQ, p.RL, tiles, partials)
         const bool dbl = M <= 8192;
-        if (relu && dbl) RLAUNCH(true, true);
-        else if (relu) RLAUNCH(true, false);
-        else if (dbl) RLAUNCH(false, true);
-        else RLAUNCH(false, false);
+        if (masky && dbl) RLAUNCH(2, true);
+        else if (masky) RLAUNCH(2, false);
+        else if (relu && dbl) RLAUNCH(1, true);
+        else if (relu) RLAUNCH(1, false);
+        else if (dbl) RLAUNCH(0, true);
+        else RLAUNCH(0, false);
 #undef RLAUNCH
         if (int e = check_launch("bn_bwd_reduce")) return e;
     }
@@ -452,17 +485,20 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
     const double inv = 1.0 / (double)M;
 #define LAUNCH(R, T, D)                                                                                          \
     hipLaunchKernelGGL((k_bn_bwd_apply<R, T, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean,    \
-                       invstd, gamma, sums, inv, dy, lddy, dres, lddres, p.CQ, p.RL)
+                       invstd, gamma, mask_scale, mask_shift, sums, inv, dy, lddy, dres, lddres, p.CQ, p.RL)
     const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
-    switch (key) {
-        case 0: LAUNCH(false, false, false); break;
-        case 1: LAUNCH(false, false, true); break;
-        case 2: LAUNCH(false, true, false); break;
-        case 3: LAUNCH(false, true, true); break;
-        case 4: LAUNCH(true, false, false); break;
-        case 5: LAUNCH(true, false, true); break;
-        case 6: LAUNCH(true, true, false); break;
-        default: LAUNCH(true, true, true); break;
+    if (masky) {
+        if (training) LAUNCH(2, true, false);
+        else LAUNCH(2, false, false);
+    } else switch (key) {
+        case 0: LAUNCH(0, false, false); break;
+        case 1: LAUNCH(0, false, true); break;
+        case 2: LAUNCH(0, true, false); break;
+        case 3: LAUNCH(0, true, true); break;
+        case 4: LAUNCH(1, false, false); break;
+        case 5: LAUNCH(1, false, true); break;
+        case 6: LAUNCH(1, true, false); break;
+        default: LAUNCH(1, true, true); break;
     }
 #undef LAUNCH
     return check_launch("bn_bwd_apply");

@@ -369,6 +369,9 @@ def bn_apply(y, coef, relu, residual=None, out=None):
     return out
 
 
+_BN_MASK_FROM_Y = os.environ.get("ISWM_BN_MASKY", "1") != "0"     # tuning switch
+
+
 def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_dres=False, dy=None):
     """Returns (dy, dres|None); writes dgamma / dbeta (length-C fp32 tensors)."""
     m, c, ldy = rows(y)
@@ -379,7 +382,11 @@ def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_d
     if dy is None:
         dy = torch.empty(y.shape, dtype=torch.float32, device=y.device)
     dres = torch.empty(y.shape, dtype=torch.float32, device=y.device) if want_dres else None
+    # ReLU without a residual: hand over the forward's scale / shift so the sign pattern is recomputed from y and the
+    # saved output is never read (a residual stage's pattern depends on the identity tensor: read `out` there)
+    masky = bool(relu) and not want_dres and _BN_MASK_FROM_Y
     call("iswm_bn_backward", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
+         _p(coef[0]) if masky else None, _p(coef[1]) if masky else None,
          int(bool(relu)), int(bool(training)), _p(dgamma), _p(dbeta), _p(dy), rows(dy)[2], _p(dres),
          rows(dres)[2] if dres is not None else 0, _p(ws), need, _stream())
     return dy, dres
