@@ -275,6 +275,39 @@ def gen_model(modeling, outdir):
         np.savez_compressed(os.path.join(outdir, "model_%s.npz" % tag), **out)
 
 
+def gen_model_v3(modeling, outdir):
+    """the other constructor path of _segm_resnet (network/modeling.py:25-56): DeepLabV3 head (name='deeplabv3',
+    ASPP -> 3x3 -> 1x1, network/_deeplab.py:71-93) on a 5-channel stem (in_channels != 3, modeling.py:25-43)."""
+    out = {}
+    cfg = ArchCfg("deeplabv3", "resnet50", 2, 16, in_channels=5)
+    m = modeling._segm_resnet("deeplabv3", "resnet50", 2, 16, False, in_channels=5)
+    sd = synth_state_dict(cfg)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m.classifier.classifier[0].project[3].p = 0.0
+    x = synth_images(4, 65, 65, seed=73, c=5)
+    labels = synth_labels(4, 65, 65, seed=73, p_fg=0.2, p_ignore=0.05)
+    out["labels"] = labels.numpy().astype(np.uint8)
+    out["keys"] = np.array(list(sd.keys()))
+    m.eval()
+    with torch.no_grad():
+        lg = m(x)
+    out["eval_logits"] = lg.numpy().copy()
+    out["eval_mask"] = lg.max(1)[1].numpy().astype(np.uint8)
+    m.train()
+    lg = m(x)
+    out["train_logits"] = lg.detach().numpy().copy()
+    loss = nn.CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]), ignore_index=255, reduction="mean")(lg, labels)
+    loss.backward()
+    out["loss"] = loss.detach().numpy()
+    params = dict(m.named_parameters())
+    for k in ("backbone.conv1.weight", "classifier.classifier.1.weight", "classifier.classifier.4.weight",
+              "classifier.classifier.4.bias", "classifier.classifier.0.project.0.weight"):
+        g = params[k].grad
+        out["grad." + k] = (g[:8] if g.dim() == 4 and g.numel() > 20000 else g).numpy().copy()
+    np.savez_compressed(os.path.join(outdir, "model_v3_in5.npz"), **out)
+
+
 OPTIM_SHAPES = [("conv1.weight", (64, 3, 7, 7)), ("bn.weight", (256,)), ("proj.weight", (48, 256, 1, 1)),
                 ("odd", (1001,))]
 OPTIM_STEPS = 3
@@ -368,6 +401,9 @@ def main():
     if args.only == "sepconv":
         gen_sepconv(deeplab, args.out)
         return
+    if args.only == "model_v3":
+        gen_model_v3(modeling, args.out)
+        return
     gen_sepconv(deeplab, args.out)
     gen_aspp(deeplab, args.out)
     gen_head(deeplab, args.out)
@@ -378,6 +414,7 @@ def main():
     gen_optim(args.out)
     if not args.skip_model:
         gen_model(modeling, args.out)
+        gen_model_v3(modeling, args.out)
     for f in sorted(os.listdir(args.out)):
         print("%-28s %8.1f KB" % (f, os.path.getsize(os.path.join(args.out, f)) / 1024))
 

@@ -509,3 +509,49 @@ def test_baseline_config0_plumbing_size():
     w = torch.tensor([1.0, 3.0])
     assert rel_err(lg, lt) <= RTOL
     assert rel_err(CrossEntropyLoss(weight=w)(lg, lab.to(dev())), oloss.weighted_ce(lt, lab, w)) <= RTOL
+
+
+def test_whole_model_v3_head_5_channel_stem():
+    """the other constructor path: modeling._segm_resnet('deeplabv3', ..., in_channels=5) -- DeepLabHead (ASPP -> 3x3 ->
+    1x1, network/_deeplab.py:71-93) on a 5-channel stem (network/modeling.py:25-43) -- same keys as the reference,
+    logits / mask / loss vs its vectors, gradients vs the oracle under the HIP path's ReLU sign patterns"""
+    from iswm_amd import ops
+    from iswm_amd.network import modeling
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.synth import ArchCfg, synth_images, synth_state_dict
+    fx = load("model_v3_in5.npz")
+    cfg = ArchCfg("deeplabv3", "resnet50", 2, 16, in_channels=5)
+    sd = synth_state_dict(cfg)
+    m = modeling._segm_resnet("deeplabv3", "resnet50", 2, 16, False, in_channels=5)
+    assert list(m.state_dict().keys()) == [str(k) for k in fx["keys"]]
+    m.load_state_dict(sd, strict=True)
+    m.classifier.classifier[0].project[3].p = 0.0
+    m = m.to(dev())
+    x = synth_images(4, 65, 65, seed=73, c=5)
+    labels = torch.from_numpy(fx["labels"].astype(np.int64))
+    m.eval()
+    with torch.no_grad():
+        lg = m(x.to(dev()))
+    assert rel_err(lg, fx["eval_logits"]) <= RTOL
+    margin = np.abs(fx["eval_logits"][:, 1] - fx["eval_logits"][:, 0])
+    sure = margin > 2 * RTOL * np.abs(fx["eval_logits"]).max()
+    assert (ops.argmax_nchw(lg).cpu().numpy()[sure] == fx["eval_mask"][sure]).all()
+    m.train()
+    with record_masks(m, "") as rec:
+        lg = m(x.to(dev()))
+    assert rel_err(lg, fx["train_logits"]) <= RTOL
+    loss = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]), ignore_index=255)(lg, labels.to(dev()))
+    assert rel_err(loss, fx["loss"]) <= RTOL
+    for p in m.parameters():
+        p.grad = None
+    up = upstream(lg.shape, 14)
+    lg.backward(up.to(dev()))
+    o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
+    o.relu_masks, o.preact = rec.masks(), {}
+    lgo = o(x)
+    lgo.backward(up)
+    check_sign_patterns(o, o.relu_masks)
+    params = dict(m.named_parameters())
+    worst = max((rel_err(params[k].grad, v.grad), k) for k, v in o.named_parameters())
+    assert worst[0] <= 3 * RTOL, worst

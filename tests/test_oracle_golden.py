@@ -221,3 +221,27 @@ def test_separable_conv_golden():
         assert rel_err(x.grad, fx[tag + ".grad_x"]) <= 2e-6, tag
         for key, t in sd.items():
             assert rel_err(t.grad, fx["%s.grad.%s" % (tag, key[len(pre):])]) <= 2e-6, (tag, key)
+
+
+def test_whole_model_v3_head_5_channel_stem():
+    """_segm_resnet(name='deeplabv3', in_channels=5): DeepLabHead (network/_deeplab.py:71-93) and the stem surgery of
+    network/modeling.py:25-43, oracle vs vectors from the reference"""
+    fx = load("model_v3_in5.npz")
+    cfg = ArchCfg("deeplabv3", "resnet50", 2, 16, in_channels=5)
+    sd = synth_state_dict(cfg)
+    assert list(sd.keys()) == [str(k) for k in fx["keys"]]
+    o = OracleDeepLab(cfg, sd, dropout_p=0.0)
+    x = synth_images(4, 65, 65, seed=73, c=5)
+    labels = torch.from_numpy(fx["labels"].astype(np.int64))
+    with torch.no_grad():
+        lg = o.eval()(x)
+    assert rel_err(lg, fx["eval_logits"]) <= 1e-4
+    o.train()
+    lg = o(x)
+    assert rel_err(lg, fx["train_logits"]) <= 1e-4
+    loss = oloss.weighted_ce(lg, labels, torch.tensor([1.0, 3.0]), 255)
+    assert rel_err(loss, fx["loss"]) <= 1e-5
+    loss.backward()
+    for k in fx.files:
+        if k.startswith("grad."):
+            check_grad(o.sd[k[5:]].grad, fx, k, 1e-3)
