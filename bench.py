@@ -60,7 +60,7 @@ def parse():
                     help="also time the same step on stock PyTorch-ROCm ops (MIOpen) on this GPU (adds ~2 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--conv-math", default=None, choices=["f32", "bf16x6"],
+    ap.add_argument("--conv-math", default=None, choices=["f32", "bf16x6", "bf16"],
                     help="convolution arithmetic (default: library default = bf16x6, or $ISWM_CONV_MATH)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra exact-fp32-MFMA measurement")
     return ap.parse_args()
@@ -208,8 +208,8 @@ def main():
     from iswm_amd.utils.loss import CrossEntropyLoss
     lib = _lib.load()
     if args.conv_math is not None:
-        lib.iswm_set_conv_math(1 if args.conv_math == "bf16x6" else 0)
-    math_name = "bf16x6" if lib.iswm_get_conv_math() == 1 else "f32"
+        lib.iswm_set_conv_math({"f32": 0, "bf16x6": 1, "bf16": 2}[args.conv_math])
+    math_name = {0: "f32", 1: "bf16x6", 2: "bf16"}[lib.iswm_get_conv_math()]
 
     torch.manual_seed(1)                                   # --random_seed 1, train.py:322
     ctor = {"resnet50": modeling.deeplabv3plus_resnet50, "resnet101": modeling.deeplabv3plus_resnet101}[args.model]
@@ -299,7 +299,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            # arithmetic type of the path: fp32 tensors and fp32-grade conv products by default; "bf16" only when the
+            # mixed-precision conv math was asked for (--conv-math bf16: bf16-rounded MFMA inputs, fp32 accumulate/storage)
+            "dtype": "bf16" if math_name == "bf16" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "deeplabv3plus_%s output_stride=%d, %dx%d synthetic tiles, %d images/GPU "
@@ -308,8 +310,9 @@ def main():
                             (args.model, args.output_stride, S, S, B,
                              "BASELINE.json configs[2]: global batch 128 over 8 GPUs" if args.model == "resnet101"
                              else "BASELINE.json configs[1]",
-                             "six bf16 MFMAs on an exact 3-way operand split (bf16x6, fp32-level error)"
-                             if math_name == "bf16x6" else "v_mfma_f32_32x32x2_f32"),
+                             {"bf16x6": "six bf16 MFMAs on an exact 3-way operand split (bf16x6, fp32-level error)",
+                              "f32": "v_mfma_f32_32x32x2_f32",
+                              "bf16": "ONE bf16 MFMA on operands rounded to bf16 (mixed precision, NOT fp32-grade)"}[math_name]),
                 "conv_math": math_name,
                 "global_batch": B * world,
                 "parallelism": "dp%d" % world,
@@ -322,12 +325,14 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             name, d = dom
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            is_x6 = "x6" in name or ", true>" in name
-            peak = X6_PEAK_TFLOPS if is_x6 else FP32_MFMA_PEAK_TFLOPS
+            is_x6 = math_name == "bf16x6" and ("x6" in name or ", true, 3>" in name)
+            is_b16 = math_name == "bf16" and ("x6" in name or ", true, 1>" in name)
+            peak = BF16_MFMA_PEAK_TFLOPS if is_b16 else (X6_PEAK_TFLOPS if is_x6 else FP32_MFMA_PEAK_TFLOPS)
             out["roofline"] = {
                 "kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "peak_basis": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 MAC (bf16x6)" if is_x6
+                "peak_basis": ("bf16 dense MFMA peak 2500 TFLOP/s" if is_b16 else
+                               "bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 MAC (bf16x6)" if is_x6
                                else "fp32 MFMA dense peak"),
                 "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": pmc_traffic(name),
@@ -361,6 +366,21 @@ def main():
             out["alt_conv_math_f32"] = {"value": round(B / dt1, 3), "unit": "images/sec",
                                         "ms_per_step": round(dt1 * 1e3, 3),
                                         "note": "identical step on v_mfma_f32_32x32x2_f32 kernels (ISWM_CONV_MATH=f32)"}
+            # and with the mixed-precision conv math of BASELINE configs[4] (reduced precision: reported, never `value`)
+            lib.iswm_set_conv_math(2)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t1) / 3
+            lib.iswm_set_conv_math(1)
+            out["alt_conv_math_bf16"] = {"value": round(B / dt2, 3), "unit": "images/sec",
+                                         "ms_per_step": round(dt2 * 1e3, 3),
+                                         "note": "identical step with bf16-rounded MFMA inputs, fp32 accumulate / storage "
+                                                 "(ISWM_CONV_MATH=bf16): mixed precision, NOT the headline arithmetic"}
         if world == 1 and args.torch_baseline:
             del model, net, opt, images, labels          # free the product's activations / arenas first
             torch.cuda.empty_cache()

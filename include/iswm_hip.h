@@ -53,6 +53,9 @@ typedef struct {
  * 1 = "bf16x6": each fp32 operand is split exactly into three bf16 pieces and the product is formed
  * from six bf16 MFMAs with fp32 accumulation (error ~1e-7 relative, i.e. fp32 level, at up to 2.7x the
  * fp32 MFMA rate).  Default 1; the environment variable ISWM_CONV_MATH=f32 selects 0 at load time.
+ * Mode 2 ("bf16", ISWM_CONV_MATH=bf16) is MIXED PRECISION, not fp32-grade: operands rounded to nearest bf16, ONE
+ * bf16 MFMA per product, fp32 accumulation and fp32 tensors -- through the packed forward / data-gradient entry
+ * points and the weight gradient; the plain entry points stay on the fp32 MFMA kernels in this mode.
  * Geometries the bf16x6 kernels do not cover (gathered channel count not a multiple of 32: the stem, the
  * 304-channel decoder input) always run on the fp32 MFMA kernels. */
 int iswm_set_conv_math(int mode);

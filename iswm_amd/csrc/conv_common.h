@@ -60,14 +60,26 @@ __device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, ui
 }
 
 
+// round-to-nearest-even conversion of 4 floats to packed bf16x4 (conv math "bf16": one plane, one MFMA per product)
+__device__ __forceinline__ uint2 round_bf16x4(const float4 v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u = __float_as_uint(x[i]);
+        r[i] = u + 0x7FFFu + ((u >> 16) & 1u);        // finite inputs; NaN payloads are not preserved
+    }
+    return make_uint2(__builtin_amdgcn_perm(r[1], r[0], 0x07060302u), __builtin_amdgcn_perm(r[3], r[2], 0x07060302u));
+}
+
 // bf16x6 path (conv_mfma_x6.hip): fp32-accurate products from six bf16 MFMAs
 bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn);
 bool launch_conv_dgrad_x6(ConvArgs a, hipStream_t s, int bm, int bn);
-bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm);
-size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad);
-void launch_pack_weights_batch(const void* jobs_dev, int njobs, int total_blocks, hipStream_t s);
+bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm, int planes);
+size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad, int planes);
+void launch_pack_weights_batch(const void* jobs_dev, int njobs, int total_blocks, int planes, hipStream_t s);
 int pack_job_blocks_x6(int Cout, int T, int Cin, bool dgrad);
-void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, hipStream_t s);
+void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s);
 void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s);
 
 // halo-patch bf16x6 kernel for stride-1 KxK filters (conv_mfma_x6p.hip)
@@ -90,7 +102,7 @@ struct PatchArgs {
     int accumulate;
 };
 bool conv_patch_plan(int RH, int RW, int KH, int KW, int dil, int* PH, int* PW);
-void launch_conv_x6_patch(PatchArgs a, bool dgrad, hipStream_t s);
+void launch_conv_x6_patch(PatchArgs a, bool dgrad, int planes, hipStream_t s);
 
 // tap-uniform fast path (conv_mfma_u.hip); each returns false when the geometry does not qualify
 bool launch_conv_fwd_u(ConvArgs a, hipStream_t s);

@@ -356,7 +356,8 @@ static __device__ __attribute__((aligned(16))) float g_zero_row_w[64];   // targ
 // memory, so the three bf16 planes are kept [k][row] in LDS (natural 8-byte writes) and the k-contiguous MFMA
 // fragments are produced by gfx950's transposing LDS read ds_read_b64_tr_b16 (4 k x 16 rows per 16 lanes);
 // row pitch 2*rows + 64 B puts the 4 k-rows of one read on disjoint bank quarters.
-template <int BM, int BN, int MODE, bool X6>
+// NP (X6 only): bf16 planes per operand -- 3 = exact split / six MFMAs (bf16x6), 1 = rounded operands / one MFMA (bf16)
+template <int BM, int BN, int MODE, bool X6, int NP = 3>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
     constexpr int MB = BM / 64, NB = BN / 64;
     constexpr int AQ = BM / 4, AKR = 256 / AQ, APASS = 32 / AKR;
@@ -367,13 +368,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
     constexpr int XPA = BM == 128 ? 256 : BM * 2 + 64, XPB = BN == 128 ? 256 : BN * 2 + 64;
     constexpr int SWA = BM == 128 ? 64 : 0, SWB = BN == 128 ? 64 : 0;   // swizzle step (bytes)
     constexpr int XPLA = 32 * XPA, XPLB = 32 * XPB;                  // X6 plane sizes (bytes)
-    constexpr int SMEM_BYTES = X6 ? 3 * (XPLA + XPLB) : 2 * 32 * (BM + BN) * 4;
+    constexpr int SMEM_BYTES = X6 ? NP * (XPLA + XPLB) : 2 * 32 * (BM + BN) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
     float* smem = reinterpret_cast<float*>(smem_raw);
     float* As = smem;
     float* Bs = smem + 2 * 32 * BM;
     unsigned char* Ax = smem_raw;               // X6: [3][32][XPA]
-    unsigned char* Bx = smem_raw + 3 * XPLA;    // X6: [3][32][XPB]
+    unsigned char* Bx = smem_raw + NP * XPLA;   // X6: [NP][32][XPB]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -489,23 +490,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
         if constexpr (X6) {
 #pragma unroll
             for (int j = 0; j < APASS; ++j) {
-                uint2 h, m, l;
-                split3(ra[j], h, m, l);
                 const int kr = ak0 + AKR * j;
                 unsigned char* p = Ax + kr * XPA + ((aq * 8) ^ ((kr & 3) * SWA));
-                *reinterpret_cast<uint2*>(p) = h;
-                *reinterpret_cast<uint2*>(p + XPLA) = m;
-                *reinterpret_cast<uint2*>(p + 2 * XPLA) = l;
+                if constexpr (NP == 1) {
+                    *reinterpret_cast<uint2*>(p) = round_bf16x4(ra[j]);
+                } else {
+                    uint2 h, m, l;
+                    split3(ra[j], h, m, l);
+                    *reinterpret_cast<uint2*>(p) = h;
+                    *reinterpret_cast<uint2*>(p + XPLA) = m;
+                    *reinterpret_cast<uint2*>(p + 2 * XPLA) = l;
+                }
             }
 #pragma unroll
             for (int j = 0; j < BPASS; ++j) {
-                uint2 h, m, l;
-                split3(rb[j], h, m, l);
                 const int kr = bk0 + BKR * j;
                 unsigned char* p = Bx + kr * XPB + ((bq * 8) ^ ((kr & 3) * SWB));
-                *reinterpret_cast<uint2*>(p) = h;
-                *reinterpret_cast<uint2*>(p + XPLB) = m;
-                *reinterpret_cast<uint2*>(p + 2 * XPLB) = l;
+                if constexpr (NP == 1) {
+                    *reinterpret_cast<uint2*>(p) = round_bf16x4(rb[j]);
+                } else {
+                    uint2 h, m, l;
+                    split3(rb[j], h, m, l);
+                    *reinterpret_cast<uint2*>(p) = h;
+                    *reinterpret_cast<uint2*>(p + XPLB) = m;
+                    *reinterpret_cast<uint2*>(p + 2 * XPLB) = l;
+                }
             }
         } else {
 #pragma unroll
@@ -567,26 +576,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvArgs a) {
                 for (int mb = 0; mb < MB; ++mb) {
                     const int c0 = wm * (BM / 2) + mb * 32;
                     ah[mb] = tr_frag(Ax, XPA, SWA, c0, ks);
-                    am[mb] = tr_frag(Ax + XPLA, XPA, SWA, c0, ks);
-                    al[mb] = tr_frag(Ax + 2 * XPLA, XPA, SWA, c0, ks);
+                    if constexpr (NP == 3) {
+                        am[mb] = tr_frag(Ax + XPLA, XPA, SWA, c0, ks);
+                        al[mb] = tr_frag(Ax + 2 * XPLA, XPA, SWA, c0, ks);
+                    }
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int c0 = wn * (BN / 2) + nb * 32;
                     bh[nb] = tr_frag(Bx, XPB, SWB, c0, ks);
-                    bm[nb] = tr_frag(Bx + XPLB, XPB, SWB, c0, ks);
-                    bl[nb] = tr_frag(Bx + 2 * XPLB, XPB, SWB, c0, ks);
+                    if constexpr (NP == 3) {
+                        bm[nb] = tr_frag(Bx + XPLB, XPB, SWB, c0, ks);
+                        bl[nb] = tr_frag(Bx + 2 * XPLB, XPB, SWB, c0, ks);
+                    }
                 }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         f32x16 c = acc[mb][nb];
-                        c = mfma_bf16(al[mb], bh[nb], c);
-                        c = mfma_bf16(ah[mb], bl[nb], c);
-                        c = mfma_bf16(am[mb], bm[nb], c);
-                        c = mfma_bf16(am[mb], bh[nb], c);
-                        c = mfma_bf16(ah[mb], bm[nb], c);
+                        if constexpr (NP == 3) {
+                            c = mfma_bf16(al[mb], bh[nb], c);
+                            c = mfma_bf16(ah[mb], bl[nb], c);
+                            c = mfma_bf16(am[mb], bm[nb], c);
+                            c = mfma_bf16(am[mb], bh[nb], c);
+                            c = mfma_bf16(ah[mb], bm[nb], c);
+                        }
                         c = mfma_bf16(ah[mb], bh[nb], c);
                         acc[mb][nb] = c;
                     }
@@ -752,16 +767,19 @@ static int g_conv_math = -1;
 static int conv_math() {
     if (g_conv_math < 0) {
         const char* e = getenv("ISWM_CONV_MATH");
-        g_conv_math = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;   // default: bf16x6
+        g_conv_math = (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0
+                      : (e && (!strcmp(e, "bf16") || !strcmp(e, "2"))) ? 2 : 1;   // default: bf16x6
     }
     return g_conv_math;
 }
 extern "C" int iswm_set_conv_math(int mode) {
-    ISWM_REQUIRE(mode == 0 || mode == 1, "set_conv_math: mode must be 0 (f32) or 1 (bf16x6)");
+    ISWM_REQUIRE(mode >= 0 && mode <= 2, "set_conv_math: mode must be 0 (f32), 1 (bf16x6) or 2 (bf16)");
     g_conv_math = mode;
     return 0;
 }
 extern "C" int iswm_get_conv_math(void) { return conv_math(); }
+// bf16 planes per operand of the packed / weight-gradient kernels under the current math: 3 (bf16x6) or 1 (bf16)
+static int math_planes() { return conv_math() == 2 ? 1 : 3; }
 
 // Halo-patch kernel applicability (stride-1 KxK, bf16x6, packed weights); ISWM_X6_PATCH=0 disables it.
 static int g_x6_patch = -1;
@@ -797,12 +815,12 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         const bool dg = kind == 4;
         int pbm, pbn;
         if (patch_plan(d, dg, &pbm, &pbn)) {
-            snprintf(buf, buflen, "k_conv_x6_patch<%s>", dg ? "true" : "false");
+            snprintf(buf, buflen, "k_conv_x6_patch<%s, %d>", dg ? "true" : "false", math_planes());
             return 0;
         }
         conv_pick_tile_x6(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, dg ? d->Cin : d->Cout,
                           d->KH * d->KW * (dg ? d->Cout : d->Cin), dg, d->KH * d->KW == 1, &pbm, &pbn);
-        snprintf(buf, buflen, "k_conv_x6<%d, 64, %s, true>", pbm, dg ? "true" : "false");
+        snprintf(buf, buflen, "k_conv_x6<%d, 64, %s, true, %d>", pbm, dg ? "true" : "false", math_planes());
         return 0;
     }
     int bm, bn;
@@ -811,7 +829,7 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         if (d->Cin % 32 == 0) {
             if (conv_math() == 1) conv_pick_tile_x6(M, d->Cout, d->KH * d->KW * d->Cin, false, d->KH * d->KW == 1, &bm, &bn);
             else conv_pick_tile(M, d->Cout, &bm, &bn);
-            snprintf(buf, buflen, conv_math() == 1 ? "k_conv_x6<%d, %d, false, false>" : "k_conv_fwd_u<%d, %d>", bm, bn);
+            snprintf(buf, buflen, conv_math() == 1 ? "k_conv_x6<%d, %d, false, false, 3>" : "k_conv_fwd_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_fwd<%d>", use_narrow_tile((M + 127) / 128, d->Cout) ? 64 : 128);
         }
@@ -820,16 +838,17 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         if (d->Cout % 32 == 0) {
             if (conv_math() == 1) conv_pick_tile_x6(M, d->Cin, d->KH * d->KW * d->Cout, true, d->KH * d->KW == 1, &bm, &bn);
             else conv_pick_tile(M, d->Cin, &bm, &bn);
-            if (conv_math() == 1) snprintf(buf, buflen, "k_conv_x6<%d, %d, true, false>", bm, bn);
+            if (conv_math() == 1) snprintf(buf, buflen, "k_conv_x6<%d, %d, true, false, 3>", bm, bn);
             else snprintf(buf, buflen, "k_conv_dgrad_u<%d, %d>", bm, bn);
         } else {
             snprintf(buf, buflen, "k_conv_dgrad<%d>", use_narrow_tile((M + 127) / 128, d->Cin) ? 64 : 128);
         }
     } else {
-        WgradPlan p = plan_wgrad(d, conv_math() == 1);
+        WgradPlan p = plan_wgrad(d, conv_math() >= 1);
         const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
         const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
-        snprintf(buf, buflen, "k_conv_wgrad<%d, %d, %d, %s>", p.bm, p.bn, mode, conv_math() == 1 ? "true" : "false");
+        snprintf(buf, buflen, "k_conv_wgrad<%d, %d, %d, %s, %d>", p.bm, p.bn, mode, conv_math() >= 1 ? "true" : "false",
+                 conv_math() == 2 ? 1 : 3);
     }
     return 0;
 }
@@ -940,18 +959,21 @@ extern "C" int iswm_conv2d_fwd_packed_stat_layout(const iswm_conv_desc* d, int* 
         *tiles = d->N * ((d->Ho + PH - 1) / PH) * ((d->Wo + PW - 1) / PW);
         *tile_rows = 0;
     } else {
-        *tile_rows = iswm_conv2d_stat_tile_rows(d);
-        *tiles = iswm_conv2d_stat_tiles(d);
+        int bm, bn;     // the tile launch_conv_x6_pk will use
+        const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+        conv_pick_tile_x6(M, d->Cout, d->KH * d->KW * d->Cin, false, d->KH * d->KW == 1, &bm, &bn);
+        *tile_rows = bm;
+        *tiles = (int)((M + bm - 1) / bm);
     }
     return 0;
 }
 
 /* ---- bf16x6 with pre-split, fragment-ordered weights ("packed"): kind 0 = forward, 1 = data gradient ---- */
 extern "C" size_t iswm_conv2d_packed_weight_bytes(const iswm_conv_desc* d, int kind) {
-    if (!d || conv_math() != 1 || (kind != 0 && kind != 1)) return 0;
+    if (!d || conv_math() < 1 || (kind != 0 && kind != 1)) return 0;
     const int gc = kind ? d->Cout : d->Cin;
     if (gc % 32 != 0) return 0;
-    return packed_weight_bytes_x6(d->Cout, d->KH * d->KW, d->Cin, kind == 1);
+    return packed_weight_bytes_x6(d->Cout, d->KH * d->KW, d->Cin, kind == 1, math_planes());
 }
 
 extern "C" int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed,
@@ -960,14 +982,14 @@ extern "C" int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const
     ISWM_REQUIRE(kind == 0 || kind == 1, "pack_weights: kind must be 0 (forward) or 1 (data gradient)");
     ISWM_REQUIRE(w && packed && aligned16(packed), "pack_weights: bad pointer");
     ISWM_REQUIRE((kind ? d->Cout : d->Cin) % 32 == 0, "pack_weights: gathered channel count must be a multiple of 32");
-    launch_pack_weights_x6(w, packed, d->Cout, d->KH * d->KW, d->Cin, kind == 1, (hipStream_t)stream);
+    launch_pack_weights_x6(w, packed, d->Cout, d->KH * d->KW, d->Cin, kind == 1, math_planes(), (hipStream_t)stream);
     return check_launch("pack_weights");
 }
 
 /* ---- batched packing: every conv of a model in one launch ---- */
 extern "C" size_t iswm_packed_weight_bytes(int Cout, int taps, int Cin, int kind) {
     if (Cout <= 0 || taps <= 0 || Cin <= 0 || (kind != 0 && kind != 1) || (kind ? Cout : Cin) % 32 != 0) return 0;
-    return packed_weight_bytes_x6(Cout, taps, Cin, kind == 1);
+    return packed_weight_bytes_x6(Cout, taps, Cin, kind == 1, math_planes());
 }
 
 extern "C" int iswm_pack_job_blocks(int Cout, int taps, int Cin, int kind) {
@@ -979,7 +1001,7 @@ extern "C" int iswm_pack_weights_batch(const iswm_pack_job* jobs_dev, int njobs,
                                        iswm_stream_t stream) {
     ISWM_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_weights_batch: bad argument");
     static_assert(sizeof(iswm_pack_job) == 40, "iswm_pack_job layout");
-    launch_pack_weights_batch(jobs_dev, njobs, total_blocks, (hipStream_t)stream);
+    launch_pack_weights_batch(jobs_dev, njobs, total_blocks, math_planes(), (hipStream_t)stream);
     return check_launch("pack_weights_batch");
 }
 
@@ -997,12 +1019,12 @@ extern "C" int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, c
     if (patch_plan(d, false, &PH, &PW)) {
         PatchArgs p = patch_args(d, false, PH, PW);
         p.x = x; p.wpk = reinterpret_cast<const uint4*>(wpk); p.bias = bias; p.y = y; p.stats = stat_partials;
-        launch_conv_x6_patch(p, false, (hipStream_t)stream);
+        launch_conv_x6_patch(p, false, math_planes(), (hipStream_t)stream);
         return check_launch("conv_fwd_patch");
     }
     int bm, bn;
     conv_pick_tile_x6(a.M, d->Cout, a.Ktot, false, d->KH * d->KW == 1, &bm, &bn);
-    launch_conv_x6_pk(a, (hipStream_t)stream, false, bm);
+    launch_conv_x6_pk(a, (hipStream_t)stream, false, bm, math_planes());
     return check_launch("conv_fwd_packed");
 }
 
@@ -1021,18 +1043,18 @@ extern "C" int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy
     if (patch_plan(d, true, &PH, &PW)) {
         PatchArgs p = patch_args(d, true, PH, PW);
         p.x = dy; p.wpk = reinterpret_cast<const uint4*>(wpk); p.y = dx; p.accumulate = accumulate;
-        launch_conv_x6_patch(p, true, (hipStream_t)stream);
+        launch_conv_x6_patch(p, true, math_planes(), (hipStream_t)stream);
         return check_launch("conv_dgrad_patch");
     }
     int bm, bn;
     conv_pick_tile_x6(a.M, d->Cin, a.Ktot, true, d->KH * d->KW == 1, &bm, &bn);
-    launch_conv_x6_pk(a, (hipStream_t)stream, true, bm);
+    launch_conv_x6_pk(a, (hipStream_t)stream, true, bm, math_planes());
     return check_launch("conv_dgrad_packed");
 }
 
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
-    WgradPlan p = plan_wgrad(d, conv_math() == 1);
+    WgradPlan p = plan_wgrad(d, conv_math() >= 1);
     if (p.nsplit <= 1) return 0;
     return (size_t)p.nsplit * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
 }
@@ -1042,7 +1064,7 @@ extern "C" int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const 
     if (int e = validate(d)) return e;
     ISWM_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
     ISWM_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw), "conv_wgrad: pointers must be 16-byte aligned");
-    WgradPlan p = plan_wgrad(d, conv_math() == 1);
+    WgradPlan p = plan_wgrad(d, conv_math() >= 1);
     const size_t need = iswm_conv2d_wgrad_workspace(d);
     ISWM_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))),
                  "conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -1056,17 +1078,19 @@ extern "C" int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const 
     dim3 grid(p.MT * p.NT, p.nsplit);
     const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
     const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
-    const bool x6 = conv_math() == 1;
-#define WLAUNCH(BM_, BN_, X_)                                                                         \
-    do {                                                                                              \
-        if (mode == 2) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 2, X_>), grid, dim3(256), 0, s, a);      \
-        else if (mode == 1) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 1, X_>), grid, dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 0, X_>), grid, dim3(256), 0, s, a);                \
+    const bool x6 = conv_math() >= 1, one = conv_math() == 2;
+#define WLAUNCH(BM_, BN_, X_, NP_)                                                                          \
+    do {                                                                                                    \
+        if (mode == 2) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 2, X_, NP_>), grid, dim3(256), 0, s, a);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 1, X_, NP_>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((k_conv_wgrad<BM_, BN_, 0, X_, NP_>), grid, dim3(256), 0, s, a);                \
     } while (0)
-    if (p.bm == 128 && x6) WLAUNCH(128, 128, true);
-    else if (p.bm == 128) WLAUNCH(128, 128, false);
-    else if (x6) WLAUNCH(64, 64, true);
-    else WLAUNCH(64, 64, false);
+    if (p.bm == 128 && one) WLAUNCH(128, 128, true, 1);
+    else if (p.bm == 128 && x6) WLAUNCH(128, 128, true, 3);
+    else if (p.bm == 128) WLAUNCH(128, 128, false, 3);
+    else if (one) WLAUNCH(64, 64, true, 1);
+    else if (x6) WLAUNCH(64, 64, true, 3);
+    else WLAUNCH(64, 64, false, 3);
 #undef WLAUNCH
     if (int e = check_launch("conv_wgrad")) return e;
     if (p.nsplit > 1) {

@@ -60,15 +60,18 @@ __device__ __forceinline__ void x6_row_pixel(int m, int N, int RH, int RW, bool 
 // BD == true ("B direct"): the weight operand was split and laid out in MFMA fragment order ahead of time
 //   (k_pack_weights_x6: [col block of 32][k block of 16][plane][lane] x 16 B), so each wave loads its B fragments
 //   straight from global/L2 into registers -- no split arithmetic, LDS write or LDS read for B.  a.w = packed.
-template <int BM, int BN, bool DGRAD, bool BD>
+// NP: bf16 planes per operand.  3 = the exact split, six MFMAs per product (fp32-grade, "bf16x6");  1 = operands rounded
+//     to nearest bf16, one MFMA per product, fp32 accumulation ("bf16": mixed precision, packed weights only).
+template <int BM, int BN, bool DGRAD, bool BD, int NP = 3>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 : 4)) void k_conv_x6(const ConvArgs a) {
+    static_assert(NP == 3 || (NP == 1 && BD), "the one-plane arithmetic exists for packed weights only");
     const int GC = DGRAD ? a.Cout : a.Cin;     // channels of the gathered operand (per tap)
     const int NC = DGRAD ? a.Cin : a.Cout;     // output columns
     constexpr int MB = BM / 64, NB = BN / 64, AR = BM / 32, BR = BN / 32;
     constexpr int PLANE_A = BM * X6_PITCH, PLANE_B = BN * X6_PITCH;          // bytes
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (PLANE_A + (BD ? 0 : PLANE_B))];
-    unsigned char* As = smem;                 // [3][BM][80 B]
-    unsigned char* Bs = smem + 3 * PLANE_A;   // [3][BN][80 B]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (PLANE_A + (BD ? 0 : PLANE_B))];
+    unsigned char* As = smem;                  // [NP][BM][80 B]
+    unsigned char* Bs = smem + NP * PLANE_A;   // [NP][BN][80 B]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
     const int taps = a.KH * a.KW;
     const int nCC = GC >> 5;
     // BD: this wave's packed fragments: column block (n0 + wn*BN/2)/32 + nb, 192 uint4 per (column block, k16)
-    const uint4* wpk = reinterpret_cast<const uint4*>(a.w) + (size_t)((n0 + wn * (BN / 2)) >> 5) * (a.Ktot >> 4) * 192 + lane;
-    const size_t wpk_nb = (size_t)(a.Ktot >> 4) * 192;
+    const uint4* wpk = reinterpret_cast<const uint4*>(a.w) + (size_t)((n0 + wn * (BN / 2)) >> 5) * (a.Ktot >> 4) * (64 * NP) + lane;
+    const size_t wpk_nb = (size_t)(a.Ktot >> 4) * (64 * NP);
 
     const float* aptr[AR];
     int astep[AR];
@@ -192,25 +195,29 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
             }
         }
     };
-    uint4 bfr[2][NB][3];   // BD: [k half][column block][plane]
+    uint4 bfr[2][NB][NP];  // BD: [k half][column block][plane]
     auto bload = [&](int k16) {   // fragments of the chunk whose first k16 block is k16 = (tap * nCC + cc) * 2
-        const uint4* p = wpk + (size_t)k16 * 192;
+        const uint4* p = wpk + (size_t)k16 * (64 * NP);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bfr[ks][nb][pl] = p[nb * wpk_nb + (ks * 3 + pl) * 64];
+                for (int pl = 0; pl < NP; ++pl) bfr[ks][nb][pl] = p[nb * wpk_nb + (ks * NP + pl) * 64];
     };
     auto lstore = [&](const float4 (&ra)[AR]) {   // split into bf16 planes and write 8 B per plane per row
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
-            uint2 h, m, l;
-            split3(ra[j], h, m, l);
             unsigned char* p = As + (r0 + 32 * j) * X6_PITCH + q * 8;
-            *reinterpret_cast<uint2*>(p) = h;
-            *reinterpret_cast<uint2*>(p + PLANE_A) = m;
-            *reinterpret_cast<uint2*>(p + 2 * PLANE_A) = l;
+            if constexpr (NP == 1) {
+                *reinterpret_cast<uint2*>(p) = round_bf16x4(ra[j]);
+            } else {
+                uint2 h, m, l;
+                split3(ra[j], h, m, l);
+                *reinterpret_cast<uint2*>(p) = h;
+                *reinterpret_cast<uint2*>(p + PLANE_A) = m;
+                *reinterpret_cast<uint2*>(p + 2 * PLANE_A) = l;
+            }
         }
         if constexpr (!BD)
 #pragma unroll
@@ -243,15 +250,19 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
             for (int mb = 0; mb < MB; ++mb) {
                 const unsigned char* p = Ab + mb * 32 * X6_PITCH + ks * 32;
                 ah[mb] = *reinterpret_cast<const uint4*>(p);
-                am[mb] = *reinterpret_cast<const uint4*>(p + PLANE_A);
-                al[mb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_A);
+                if constexpr (NP == 3) {
+                    am[mb] = *reinterpret_cast<const uint4*>(p + PLANE_A);
+                    al[mb] = *reinterpret_cast<const uint4*>(p + 2 * PLANE_A);
+                }
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 if constexpr (BD) {
                     bh[nb] = bfr[ks][nb][0];
-                    bm[nb] = bfr[ks][nb][1];
-                    bl[nb] = bfr[ks][nb][2];
+                    if constexpr (NP == 3) {
+                        bm[nb] = bfr[ks][nb][1];
+                        bl[nb] = bfr[ks][nb][2];
+                    }
                 } else {
                     const unsigned char* p = Bb + nb * 32 * X6_PITCH + ks * 32;
                     bh[nb] = *reinterpret_cast<const uint4*>(p);
@@ -264,11 +275,13 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (BM == 128 ? 3 
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f32x16 c = acc[mb][nb];
-                    c = mfma_bf16(al[mb], bh[nb], c);     // smallest terms first
-                    c = mfma_bf16(ah[mb], bl[nb], c);
-                    c = mfma_bf16(am[mb], bm[nb], c);
-                    c = mfma_bf16(am[mb], bh[nb], c);
-                    c = mfma_bf16(ah[mb], bm[nb], c);
+                    if constexpr (NP == 3) {
+                        c = mfma_bf16(al[mb], bh[nb], c);     // smallest terms first
+                        c = mfma_bf16(ah[mb], bl[nb], c);
+                        c = mfma_bf16(am[mb], bm[nb], c);
+                        c = mfma_bf16(am[mb], bh[nb], c);
+                        c = mfma_bf16(ah[mb], bm[nb], c);
+                    }
                     c = mfma_bf16(ah[mb], bh[nb], c);
                     acc[mb][nb] = c;
                 }
@@ -387,7 +400,7 @@ bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn) {
 }
 
 // packed-weight ("B direct") launchers: a.w = k_pack_weights_x6 output.  Tiles: 128x64 or 64x64.
-bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm) {
+bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm, int planes) {
     static int parity = -1;
     if (parity < 0) {
         const char* e = getenv("ISWM_X6_PARITY");
@@ -398,6 +411,16 @@ bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm) {
     a.MT = (a.M + bm - 1) / bm;
     a.NT = (nc + 63) / 64;
     dim3 grid(a.MT * a.NT), blk(256);
+    if (planes == 1) {
+        if (dgrad) {
+            if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, true, true, 1>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((k_conv_x6<64, 64, true, true, 1>), grid, blk, 0, s, a);
+        } else {
+            if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, false, true, 1>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((k_conv_x6<64, 64, false, true, 1>), grid, blk, 0, s, a);
+        }
+        return true;
+    }
     if (dgrad) {
         if (bm == 128) hipLaunchKernelGGL((k_conv_x6<128, 64, true, true>), grid, blk, 0, s, a);
         else hipLaunchKernelGGL((k_conv_x6<64, 64, true, true>), grid, blk, 0, s, a);
@@ -413,7 +436,7 @@ bool launch_conv_x6_pk(ConvArgs a, hipStream_t s, bool dgrad, int bm) {
 //   dgrad: column = cin,  k = (tap, cout)  from the same tensor (implicit transpose)
 // packed[((cb * K16 + k16) * 3 + plane) * 64 + lane] (uint4) holds, for column cb*32 + (lane & 31), the 8 bf16 of
 // plane {hi, mid, lo} at k = k16*16 + 8*(lane >> 5) .. +7.  Columns >= NC are zero; cb runs to ceil(NC/64)*2.
-template <bool DGRAD>
+template <bool DGRAD, int NP>
 __device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int T,
                                                   int Cin, int K16, int idx) {
     const int lane = idx & 63, f = idx >> 6;
@@ -428,21 +451,26 @@ __device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, u
         if (col < NC) x = DGRAD ? w[((size_t)(g0 + i) * T + tap) * Cin + col] : w[((size_t)col * T + tap) * Cin + g0 + i];
         v[i] = x;
     }
-    uint2 h0, m0, l0, h1, m1, l1;
-    split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-    split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-    uint4* o = packed + (size_t)f * 192 + lane;
-    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    uint4* o = packed + (size_t)f * (64 * NP) + lane;
+    if constexpr (NP == 1) {
+        const uint2 r0 = round_bf16x4(make_float4(v[0], v[1], v[2], v[3])), r1 = round_bf16x4(make_float4(v[4], v[5], v[6], v[7]));
+        o[0] = make_uint4(r0.x, r0.y, r1.x, r1.y);
+    } else {
+        uint2 h0, m0, l0, h1, m1, l1;
+        split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+        split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
 }
 
-template <bool DGRAD>
+template <bool DGRAD, int NP>
 __global__ __launch_bounds__(256) void k_pack_weights_x6(const float* __restrict__ w, uint4* __restrict__ packed,
                                                          int Cout, int T, int Cin, int K16, int total) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    pack_weights_body<DGRAD>(w, packed, Cout, T, Cin, K16, idx);
+    pack_weights_body<DGRAD, NP>(w, packed, Cout, T, Cin, K16, idx);
 }
 
 // All conv weights of a model in ONE launch (a training step otherwise issues ~220 tiny pack kernels, each mostly
@@ -454,6 +482,7 @@ struct PackJob {             // mirrors iswm_pack_job
     int first_block, reserved;
 };
 
+template <int NP>
 __global__ __launch_bounds__(256) void k_pack_weights_batch(const PackJob* __restrict__ jobs, int njobs) {
     int lo = 0, hi = njobs - 1;
     const int b = blockIdx.x;
@@ -467,12 +496,13 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const PackJob* __res
     const int cbs = ((NC + 63) / 64) * 2, K16 = j.T * GC / 16;
     const int idx = (b - j.first_block) * 256 + threadIdx.x;
     if (idx >= cbs * K16 * 64) return;
-    if (j.kind) pack_weights_body<true>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);
-    else pack_weights_body<false>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);
+    if (j.kind) pack_weights_body<true, NP>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);
+    else pack_weights_body<false, NP>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);
 }
 
-void launch_pack_weights_batch(const void* jobs_dev, int njobs, int total_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_pack_weights_batch, dim3(total_blocks), dim3(256), 0, s, (const PackJob*)jobs_dev, njobs);
+void launch_pack_weights_batch(const void* jobs_dev, int njobs, int total_blocks, int planes, hipStream_t s) {
+    if (planes == 1) hipLaunchKernelGGL(k_pack_weights_batch<1>, dim3(total_blocks), dim3(256), 0, s, (const PackJob*)jobs_dev, njobs);
+    else hipLaunchKernelGGL(k_pack_weights_batch<3>, dim3(total_blocks), dim3(256), 0, s, (const PackJob*)jobs_dev, njobs);
 }
 
 int pack_job_blocks_x6(int Cout, int T, int Cin, bool dgrad) {
@@ -481,19 +511,25 @@ int pack_job_blocks_x6(int Cout, int T, int Cin, bool dgrad) {
     return (int)((total + 255) / 256);
 }
 
-size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad) {
+size_t packed_weight_bytes_x6(int Cout, int T, int Cin, bool dgrad, int planes) {
     const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
     const size_t cbs = (size_t)((NC + 63) / 64) * 2, K16 = (size_t)T * GC / 16;
-    return cbs * K16 * 192 * sizeof(uint4);
+    return cbs * K16 * 64 * planes * sizeof(uint4);
 }
 
-void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, hipStream_t s) {
+void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s) {
     const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
     const int cbs = ((NC + 63) / 64) * 2, K16 = T * GC / 16;
     const int total = cbs * K16 * 64;
     dim3 grid((total + 255) / 256), blk(256);
-    if (dgrad) hipLaunchKernelGGL((k_pack_weights_x6<true>), grid, blk, 0, s, w, (uint4*)packed, Cout, T, Cin, K16, total);
-    else hipLaunchKernelGGL((k_pack_weights_x6<false>), grid, blk, 0, s, w, (uint4*)packed, Cout, T, Cin, K16, total);
+    uint4* o = (uint4*)packed;
+    if (planes == 1) {
+        if (dgrad) hipLaunchKernelGGL((k_pack_weights_x6<true, 1>), grid, blk, 0, s, w, o, Cout, T, Cin, K16, total);
+        else hipLaunchKernelGGL((k_pack_weights_x6<false, 1>), grid, blk, 0, s, w, o, Cout, T, Cin, K16, total);
+    } else {
+        if (dgrad) hipLaunchKernelGGL((k_pack_weights_x6<true, 3>), grid, blk, 0, s, w, o, Cout, T, Cin, K16, total);
+        else hipLaunchKernelGGL((k_pack_weights_x6<false, 3>), grid, blk, 0, s, w, o, Cout, T, Cin, K16, total);
+    }
 }
 
 // a: as prepared by iswm_conv2d_dgrad (a.x = dy with pitch a.ldx, a.y = dx with pitch a.ldy, a.M = N*H*W),

@@ -26,9 +26,10 @@ constexpr int XP_PASSES = (XP_HPMAX + 31) / 32;
 constexpr int XP_PLANE = XP_HPMAX * XP_PITCH;
 
 
-template <bool DGRAD>
+// NP: bf16 planes per operand -- 3 = exact split, six MFMAs per product (bf16x6); 1 = operands rounded to bf16, one MFMA
+template <bool DGRAD, int NP>
 __global__ __launch_bounds__(256, 3) void k_conv_x6_patch(const PatchArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[3 * XP_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char As[NP * XP_PLANE];
     __shared__ int rowpix[128];          // output pixel index of each tile row, -1 = no such pixel
     __shared__ float red[4 * 64];
 
@@ -84,12 +85,16 @@ __global__ __launch_bounds__(256, 3) void k_conv_x6_patch(const PatchArgs a) {
 #pragma unroll
         for (int j = 0; j < XP_PASSES; ++j)
             if (j < npass && r0 + 32 * j < XP_HPMAX) {
-                uint2 h, m, l;
-                split3(ra[j], h, m, l);
                 unsigned char* p = As + (r0 + 32 * j) * XP_PITCH + q * 8;
-                *reinterpret_cast<uint2*>(p) = h;
-                *reinterpret_cast<uint2*>(p + XP_PLANE) = m;
-                *reinterpret_cast<uint2*>(p + 2 * XP_PLANE) = l;
+                if constexpr (NP == 1) {
+                    *reinterpret_cast<uint2*>(p) = round_bf16x4(ra[j]);
+                } else {
+                    uint2 h, m, l;
+                    split3(ra[j], h, m, l);
+                    *reinterpret_cast<uint2*>(p) = h;
+                    *reinterpret_cast<uint2*>(p + XP_PLANE) = m;
+                    *reinterpret_cast<uint2*>(p + 2 * XP_PLANE) = l;
+                }
             }
     };
 
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_x6_patch(const PatchArgs a) {
     const int taps = a.KH * a.KW;
     const int nCC = a.GC >> 5;
     // packed weights: 192 uint4 per (column block of 32, k16); this wave's column block = (n0 + wn*32) / 32
-    const uint4* wpk = a.wpk + (size_t)((n0 >> 5) + wn) * ((size_t)taps * a.GC >> 4) * 192 + lane;
+    const uint4* wpk = a.wpk + (size_t)((n0 >> 5) + wn) * ((size_t)taps * a.GC >> 4) * (64 * NP) + lane;
 
     f32x16 acc[2];
 #pragma unroll
@@ -114,14 +119,14 @@ __global__ __launch_bounds__(256, 3) void k_conv_x6_patch(const PatchArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     struct BFrag {
-        uint4 v[2][3];   // [k half][plane]
+        uint4 v[2][NP];  // [k half][plane]
     };
     auto bload = [&](BFrag& b, int tap, int cc) {
-        const uint4* p = wpk + (size_t)((tap * nCC + cc) * 2) * 192;
+        const uint4* p = wpk + (size_t)((tap * nCC + cc) * 2) * (64 * NP);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b.v[ks][pl] = p[(ks * 3 + pl) * 64];
+            for (int pl = 0; pl < NP; ++pl) b.v[ks][pl] = p[(ks * NP + pl) * 64];
     };
     auto tap_off = [&](int tap) -> int {
         int kh = tap / a.KW, kw = tap - kh * a.KW;
@@ -140,17 +145,21 @@ __global__ __launch_bounds__(256, 3) void k_conv_x6_patch(const PatchArgs a) {
             for (int mb = 0; mb < 2; ++mb) {
                 const unsigned char* p = As + hb[mb] + off + ks * 32;
                 ah[mb] = *reinterpret_cast<const uint4*>(p);
-                am[mb] = *reinterpret_cast<const uint4*>(p + XP_PLANE);
-                al[mb] = *reinterpret_cast<const uint4*>(p + 2 * XP_PLANE);
+                if constexpr (NP == 3) {
+                    am[mb] = *reinterpret_cast<const uint4*>(p + XP_PLANE);
+                    al[mb] = *reinterpret_cast<const uint4*>(p + 2 * XP_PLANE);
+                }
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 f32x16 c = acc[mb];
-                c = mfma_bf16(al[mb], b.v[ks][0], c);     // smallest terms first
-                c = mfma_bf16(ah[mb], b.v[ks][2], c);
-                c = mfma_bf16(am[mb], b.v[ks][1], c);
-                c = mfma_bf16(am[mb], b.v[ks][0], c);
-                c = mfma_bf16(ah[mb], b.v[ks][1], c);
+                if constexpr (NP == 3) {
+                    c = mfma_bf16(al[mb], b.v[ks][0], c);     // smallest terms first
+                    c = mfma_bf16(ah[mb], b.v[ks][2], c);
+                    c = mfma_bf16(am[mb], b.v[ks][1], c);
+                    c = mfma_bf16(am[mb], b.v[ks][0], c);
+                    c = mfma_bf16(ah[mb], b.v[ks][1], c);
+                }
                 c = mfma_bf16(ah[mb], b.v[ks][0], c);
                 acc[mb] = c;
             }
@@ -251,7 +260,7 @@ bool conv_patch_plan(int RH, int RW, int KH, int KW, int dil, int* PH, int* PW) 
 
 // a: fields x, wpk, bias, y, stats, N, RH, RW, GH, GW, GC, NC, KH, KW, dil, orgh, orgw, flip, ldg, ldo, accumulate
 // set by the caller; PH/PW from conv_patch_plan.
-void launch_conv_x6_patch(PatchArgs a, bool dgrad, hipStream_t s) {
+void launch_conv_x6_patch(PatchArgs a, bool dgrad, int planes, hipStream_t s) {
     a.HH = a.PH + a.dil * (a.KH - 1);
     a.HW = a.PW + a.dil * (a.KW - 1);
     a.TPY = (a.RH + a.PH - 1) / a.PH;
@@ -259,8 +268,13 @@ void launch_conv_x6_patch(PatchArgs a, bool dgrad, hipStream_t s) {
     a.MT = a.N * a.TPY * a.TPX;
     a.NT = (a.NC + 63) / 64;
     dim3 grid(a.MT * a.NT), blk(256);
-    if (dgrad) hipLaunchKernelGGL((k_conv_x6_patch<true>), grid, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_conv_x6_patch<false>), grid, blk, 0, s, a);
+    if (planes == 1) {
+        if (dgrad) hipLaunchKernelGGL((k_conv_x6_patch<true, 1>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_conv_x6_patch<false, 1>), grid, blk, 0, s, a);
+    } else {
+        if (dgrad) hipLaunchKernelGGL((k_conv_x6_patch<true, 3>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_conv_x6_patch<false, 3>), grid, blk, 0, s, a);
+    }
 }
 
 }  // namespace iswm

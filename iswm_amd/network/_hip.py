@@ -453,9 +453,10 @@ class WeightPacker(object):
 
     def begin(self):
         from .. import _lib
-        if _lib.load().iswm_get_conv_math() != 1 or not ops._USE_PACKED or not self.convs or not _BATCH_PACK:
+        math = _lib.load().iswm_get_conv_math()
+        if math < 1 or not ops._USE_PACKED or not self.convs or not _BATCH_PACK:
             return
-        key = tuple(m.weight.data_ptr() for m in self.convs)
+        key = (math,) + tuple(m.weight.data_ptr() for m in self.convs)      # bf16x6 packs 3 planes, bf16 one
         if key != self.key:
             self._build(self.convs[0].weight.device)
             self.key = key

@@ -31,6 +31,7 @@ class OracleDeepLab:
                 t.requires_grad_(True)
             self.sd[k] = t
         self.training = False
+        self.conv_math = "f32"      # "bf16": see _conv
         self.dropout_p = dropout_p  # nn.Dropout(0.1), network/_deeplab.py:165
         # Optional {site: bool NCHW mask}: when given, every ReLU uses the SUPPLIED sign pattern
         # (z * mask) instead of its own (z > 0).  Tests pass the HIP path's masks here so that
@@ -81,7 +82,18 @@ class OracleDeepLab:
                             self.training, BN_MOMENTUM, BN_EPS)
 
     def _conv(self, x, key, stride=1, padding=0, dilation=1, bias=None):
-        return F.conv2d(x, self.sd[key], bias, stride, padding, dilation)
+        w = self.sd[key]
+        if self.conv_math == "bf16":
+            # mixed-precision arithmetic of the product's conv math 2 (no counterpart in the reference -- BASELINE
+            # configs[4]): matrix operands rounded to bf16, exact products, fp32 accumulation.  Which of the three GEMMs
+            # of a conv take rounded operands follows the product: the forward when the (padded) input channel count is
+            # 32-aligned (everything but the stem; the decoder's 304 is padded to 320), the data gradient when Cout is
+            # 32-aligned (not the 48-wide projection or the classifier), the weight gradient always.
+            cin = w.shape[1]
+            cin_p = cin if (cin % 32 == 0 or cin < 128) else (cin + 31) // 32 * 32
+            y = _Bf16Conv.apply(x, w, stride, padding, dilation, cin_p % 32 == 0, w.shape[0] % 32 == 0)
+            return y if bias is None else y + bias.view(1, -1, 1, 1)
+        return F.conv2d(x, w, bias, stride, padding, dilation)
 
     def _bottleneck(self, x, pre, stride, dilation, down):
         """Bottleneck.forward, network/backbone/resnet.py:99-120."""
@@ -150,6 +162,33 @@ class OracleDeepLab:
         return F.interpolate(y, size=input_shape, mode="bilinear", align_corners=False)
 
     __call__ = forward
+
+
+class _Bf16Conv(torch.autograd.Function):
+    """conv2d whose GEMMs (forward, data gradient, weight gradient) take bf16-rounded operands and accumulate in fp32 --
+    what iswm_set_conv_math(2) computes; the flags keep a GEMM in fp32 where the product does."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, dilation, fwd_bf16, dgrad_bf16):
+        r = lambda t: t.bfloat16().float()
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, padding, dilation, dgrad_bf16)
+        if not fwd_bf16:
+            return F.conv2d(x, w, None, stride, padding, dilation)
+        return F.conv2d(r(x), r(w), None, stride, padding, dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, dgrad_bf16 = ctx.geom
+        r = lambda t: t.bfloat16().float()
+        dyr = r(dy)
+        if dgrad_bf16:
+            dx = torch.nn.grad.conv2d_input(x.shape, r(w), dyr, stride, padding, dilation)
+        else:
+            dx = torch.nn.grad.conv2d_input(x.shape, w, dy, stride, padding, dilation)
+        dw = torch.nn.grad.conv2d_weight(r(x), w.shape, dyr, stride, padding, dilation)
+        return dx, dw, None, None, None, None, None
 
 
 def argmax_mask(logits):

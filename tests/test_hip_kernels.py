@@ -114,6 +114,45 @@ def test_conv_fwd_dgrad_wgrad(case, conv_math):
     assert rel_err(dw.cpu().permute(0, 3, 1, 2), wr.grad) < 5e-5
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] % 32 == 0],
+                         ids=lambda c: "cin%d_cout%d_k%d_s%d_d%d_h%d" % (c[0], c[1], c[2], c[3], c[5], c[6]))
+def test_conv_bf16_mixed_precision(case):
+    """conv math 2 ("bf16", BASELINE configs[4]): operands rounded to nearest bf16, ONE MFMA per product, fp32
+    accumulation.  The oracle is therefore torch's fp32 conv on bf16-ROUNDED operands (products of bf16 values are exact
+    in fp32), for the forward, the data gradient and the weight gradient -- tight tolerances, not bf16-sized ones."""
+    from iswm_amd import _lib, ops
+    cin, cout, k, s, p, d, h, w, n = case
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2) * (2.0 / (cin * k * k)) ** 0.5
+    r = lambda t: t.bfloat16().float()                       # round to nearest even, as the kernels do
+    xr, wr = r(x).requires_grad_(True), r(wt).requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, s, p, d)
+    dy = rnd(*y_ref.shape, seed=3)
+    y_ref.backward(r(dy))
+    lib = _lib.load()
+    old = lib.iswm_get_conv_math()
+    lib.iswm_set_conv_math(2)
+    try:
+        xh = nhwc(x)
+        w_ohwi = wt.permute(0, 2, 3, 1).contiguous().to(dev())
+        g = ops.ConvGeom(xh, cout, k, k, s, p, d)
+        y, partials, tiles = ops.conv2d_fwd(xh, w_ohwi, g, want_stats=True)
+        assert rel_err(nchw(y), y_ref) < 2e-5
+        coef = ops.bn_finalize(partials, tiles[0], n * g.ho * g.wo, tiles[1], None, None, None, None, 0.1)
+        assert rel_err(coef[2], y_ref.detach().double().mean((0, 2, 3))) < 1e-5
+        dyh = nhwc(dy)
+        dx = ops.conv2d_dgrad(dyh, w_ohwi, g, tuple(xh.shape))
+        if cout % 32 == 0:                                   # otherwise the data gradient runs on the fp32 kernels
+            assert rel_err(nchw(dx), xr.grad) < 2e-5
+        dw = ops.conv2d_wgrad(xh, dyh, g)
+        assert rel_err(dw.cpu().permute(0, 3, 1, 2), wr.grad) < 5e-5
+        # and it IS reduced precision: measurably different from the fp32 product
+        y32 = F.conv2d(x, wt, None, s, p, d)
+        assert 1e-4 < rel_err(nchw(y), y32) < 3e-2
+    finally:
+        lib.iswm_set_conv_math(old)
+
+
 @pytest.mark.parametrize("conv_math", [0, 1, 2], indirect=True, ids=["f32mfma", "bf16x6", "bf16x6-plainw"])
 def test_conv_pitched_slices_and_bias(conv_math):
     """reads a channel slice of a wider buffer and writes into a slice (torch.cat elimination)"""

@@ -245,3 +245,31 @@ def test_whole_model_v3_head_5_channel_stem():
     for k in fx.files:
         if k.startswith("grad."):
             check_grad(o.sd[k[5:]].grad, fx, k, 1e-3)
+
+
+def test_bf16_conv_oracle_definition():
+    """oracle/deeplab.py _Bf16Conv (the checker of the product's mixed-precision conv math 2; the reference has no such
+    mode): forward = fp32 conv of bf16-rounded operands, backward = the two gradient GEMMs on bf16-rounded operands --
+    checked against autograd of the rounded-operand conv fed a pre-rounded upstream gradient."""
+    import torch.nn.functional as F
+    from oracle.deeplab import _Bf16Conv
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 9, 11, generator=g)
+    w = torch.randn(48, 32, 3, 3, generator=g) * 0.1
+    dy = torch.randn(2, 48, 9, 11, generator=g)
+    r = lambda t: t.bfloat16().float()
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = _Bf16Conv.apply(xa, wa, 1, 2, 2, True, True)
+    y.backward(dy)
+    xr, wr = r(x).requires_grad_(True), r(w).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 2, 2)
+    yr.backward(r(dy))
+    assert torch.equal(y.detach(), yr.detach())
+    assert rel_err(xa.grad, xr.grad) <= 1e-6 and rel_err(wa.grad, wr.grad) <= 1e-6
+    assert 1e-4 < rel_err(y.detach(), F.conv2d(x, w, None, 1, 2, 2)) < 3e-2          # it is NOT the fp32 conv
+    # flags: a GEMM the product keeps in fp32 stays in fp32
+    xb, wb = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y2 = _Bf16Conv.apply(xb, wb, 1, 2, 2, False, False)
+    assert torch.equal(y2.detach(), F.conv2d(x, w, None, 1, 2, 2))
+    y2.backward(dy)
+    assert rel_err(xb.grad, torch.nn.grad.conv2d_input(x.shape, w, dy, 1, 2, 2)) <= 1e-6
