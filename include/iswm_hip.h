@@ -151,7 +151,7 @@ int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t count, int
 int iswm_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,
                         float* save_mean, float* save_invstd, iswm_stream_t stream);
-/* out = act((y - mean[c])*scale[c] + shift[c] (+ residual)); act = relu if relu != 0 */
+/* out = act((y - mean[c])*scale[c] + shift[c] (+ residual)); act = relu if relu != 0  * relu: 0 none, 1 ReLU, 6 ReLU6 (clamp to [0, 6]; its backward passes the gradient where 0 < out < 6). */
 int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift,
                   const float* mean, const float* residual, int ldr, int relu, float* out, int ldo,
                   iswm_stream_t stream);

@@ -133,7 +133,8 @@ __global__ void k_bn_eval_coeffs(int C, const float* gamma, const float* beta, c
 }
 
 // ---- out = act(y*scale + shift (+ residual)) -------------------------------------------------
-template <bool RELU, bool RES>
+// RELU: 0 none, 1 ReLU, 2 ReLU6 (clamp to [0, 6])
+template <int RELU, bool RES>
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, int64_t M, int C4, int ldy,
                                                   const float* __restrict__ scale,
                                                   const float* __restrict__ shift,
@@ -155,6 +156,9 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
         }
         if (RELU) {
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        if (RELU == 2) {
+            o.x = fminf(o.x, 6.f); o.y = fminf(o.y, 6.f); o.z = fminf(o.z, 6.f); o.w = fminf(o.w, 6.f);
         }
         st4(out + r * ldo + c, o);
     }
@@ -202,6 +206,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
                         float4 o = ld4(out + rr * ldo + c);
                         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
                         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+                    } else if (RELU == 3) {         // ReLU6: the gradient passes where 0 < out < 6
+                        float4 o = ld4(out + rr * ldo + c);
+                        g.x = (o.x > 0.f && o.x < 6.f) ? g.x : 0.f; g.y = (o.y > 0.f && o.y < 6.f) ? g.y : 0.f;
+                        g.z = (o.z > 0.f && o.z < 6.f) ? g.z : 0.f; g.w = (o.w > 0.f && o.w < 6.f) ? g.w : 0.f;
                     } else if (RELU == 2) {
                         g.x = (v.x - mu.x) * msc.x + msh.x > 0.f ? g.x : 0.f;
                         g.y = (v.y - mu.y) * msc.y + msh.y > 0.f ? g.y : 0.f;
@@ -325,6 +333,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
             float4 o = ld4(out + r * ldo + c);
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        } else if (RELU == 3) {
+            float4 o = ld4(out + r * ldo + c);
+            g.x = (o.x > 0.f && o.x < 6.f) ? g.x : 0.f; g.y = (o.y > 0.f && o.y < 6.f) ? g.y : 0.f;
+            g.z = (o.z > 0.f && o.z < 6.f) ? g.z : 0.f; g.w = (o.w > 0.f && o.w < 6.f) ? g.w : 0.f;
         } else if (RELU == 2) {
             g.x = (v.x - mu.x) * msc.x + msh.x > 0.f ? g.x : 0.f;
             g.y = (v.y - mu.y) * msc.y + msh.y > 0.f ? g.y : 0.f;
@@ -424,10 +436,13 @@ extern "C" int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const fl
     hipLaunchKernelGGL((k_bn_apply<R, S>), grid, blk, 0, s, y, M, p.C4, ldy, scale, shift, mean, residual, ldr, out, \
                        ldo, \
                        p.CQ, p.RL)
-    if (relu && residual) LAUNCH(true, true);
-    else if (relu) LAUNCH(true, false);
-    else if (residual) LAUNCH(false, true);
-    else LAUNCH(false, false);
+    ISWM_REQUIRE(relu == 0 || relu == 1 || relu == 6, "bn_apply: relu must be 0 (none), 1 (ReLU) or 6 (ReLU6)");
+    if (relu == 6 && residual) LAUNCH(2, true);
+    else if (relu == 6) LAUNCH(2, false);
+    else if (relu && residual) LAUNCH(1, true);
+    else if (relu) LAUNCH(1, false);
+    else if (residual) LAUNCH(0, true);
+    else LAUNCH(0, false);
 #undef LAUNCH
     return check_launch("bn_apply");
 }
@@ -445,7 +460,9 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
                                 iswm_stream_t stream) {
     if (int e = chk_rows("bn_backward", M, C, ldy)) return e;
     // ReLU without a residual: the sign pattern is recomputed from y when the forward's scale / shift are given
-    const bool masky = relu && !dres && mask_scale && mask_shift;
+    ISWM_REQUIRE(relu == 0 || relu == 1 || relu == 6, "bn_backward: relu must be 0 (none), 1 (ReLU) or 6 (ReLU6)");
+    const bool relu6 = relu == 6;
+    const bool masky = relu == 1 && !dres && mask_scale && mask_shift;
     ISWM_REQUIRE(dout && y && mean && invstd && dgamma && dbeta && dy && workspace && (!relu || out || masky),
                  "bn_backward: null pointer");
     ISWM_REQUIRE(ldd % 4 == 0 && ldd >= C && lddy % 4 == 0 && lddy >= C && (!relu || (ldo % 4 == 0 && ldo >= C)) &&
@@ -464,7 +481,9 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
     hipLaunchKernelGGL((k_bn_bwd_reduce<R, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean, invstd, \
                        mask_scale, mask_shift, p.CQ, p.RL, tiles, partials)
         const bool dbl = M <= 8192;
-        if (masky && dbl) RLAUNCH(2, true);
+        if (relu6 && dbl) RLAUNCH(3, true);
+        else if (relu6) RLAUNCH(3, false);
+        else if (masky && dbl) RLAUNCH(2, true);
         else if (masky) RLAUNCH(2, false);
         else if (relu && dbl) RLAUNCH(1, true);
         else if (relu) RLAUNCH(1, false);
@@ -487,7 +506,12 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
     hipLaunchKernelGGL((k_bn_bwd_apply<R, T, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean,    \
                        invstd, gamma, mask_scale, mask_shift, sums, inv, dy, lddy, dres, lddres, p.CQ, p.RL)
     const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
-    if (masky) {
+    if (relu6) {
+        if (training && dres) LAUNCH(3, true, true);
+        else if (training) LAUNCH(3, true, false);
+        else if (dres) LAUNCH(3, false, true);
+        else LAUNCH(3, false, false);
+    } else if (masky) {
         if (training) LAUNCH(2, true, false);
         else LAUNCH(2, false, false);
     } else switch (key) {

@@ -288,6 +288,11 @@ class ReLU(nn.ReLU):
     pass
 
 
+class ReLU6(nn.ReLU6):
+    """nn.ReLU6 (MobileNetV2's activation): fused into the BatchNorm pass like ReLU (clamp to [0, 6])"""
+    pass
+
+
 class Dropout(HipModule, nn.Dropout):
     """nn.Dropout(p) (network/_deeplab.py:165) with a Philox counter mask."""
 
@@ -323,10 +328,18 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
     if isinstance(conv, SeparableBase):         # depthwise first, then the pointwise conv carries the fused BN
         sep, conv = conv, conv.body[1]
         x = sep.body[0].fwd(x, save)
-    g = conv.geometry(x)
     training = bn.training
     if bn.momentum is None or not bn.track_running_stats or not bn.affine:
         raise NotImplementedError("HIP BatchNorm2d supports affine=True, momentum!=None, running stats")
+    if isinstance(conv, DepthwiseConv2d):       # depthwise conv -> BN (MobileNetV2): statistics from a column pass
+        g = conv.geometry(x)
+        y = conv.fwd(x, save)
+        partials, tiles = None, (0, 0)
+        if training:
+            partials, nt, tr = ops.colstat(y)
+            tiles = (nt, tr)
+        return _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, True)
+    g = conv.geometry(x)
     if conv.bias is None:
         y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training, wpk=conv.packed(0))
     else:
@@ -337,6 +350,10 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
         if training:
             partials, nt, tr = ops.colstat(y)
             tiles = (nt, tr)
+    return _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, False)
+
+
+def _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, dw):
     if training:
         count = y.shape[0] * y.shape[1] * y.shape[2]
         if count <= 1:
@@ -351,10 +368,10 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
         coef = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     o = ops.bn_apply(y, coef, relu, residual, out)
     if MASK_RECORDER is not None and relu:
-        MASK_RECORDER[bn] = (o > 0)
+        MASK_RECORDER[bn] = (o > 0) & (o < 6) if relu == 6 and relu is not True else (o > 0)
     ctx = None
     if save:
-        ctx = dict(x=x, y=y, out=o, coef=coef, g=g, relu=relu, training=training, res=residual is not None, sep=sep)
+        ctx = dict(x=x, y=y, out=o, coef=coef, g=g, relu=relu, training=training, res=residual is not None, sep=sep, dw=dw)
     return o, ctx
 
 
@@ -373,6 +390,8 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
         sink.done(gw)
     if gb.requires_grad:
         sink.done(gb)
+    if ctx.get("dw"):
+        return conv.bwd(dy, sink, need_dx, dx, accumulate), dres
     conv.write_wgrad(x, dy, g, sink)
     if conv.bias is not None and conv.bias.requires_grad:
         sink.target(conv.bias).copy_(ops.colsum(dy)[:conv.out_channels])
@@ -486,8 +505,10 @@ class HipSequential(HipModule, nn.Sequential):
         st, i = [], 0
         while i < len(mods):
             m = mods[i]
-            if isinstance(m, (Conv2d, SeparableBase)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
-                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            if isinstance(m, (Conv2d, SeparableBase, DepthwiseConv2d)) and i + 1 < len(mods) and \
+                    isinstance(mods[i + 1], nn.BatchNorm2d):
+                act = mods[i + 2] if i + 2 < len(mods) else None
+                relu = 6 if isinstance(act, nn.ReLU6) else isinstance(act, nn.ReLU)
                 st.append(("cba", m, mods[i + 1], relu))
                 i += 3 if relu else 2
             elif isinstance(m, Conv2d):

@@ -354,6 +354,11 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
     return coef
 
 
+def _relu_code(relu):
+    """activation after a BatchNorm: False / 0 none, True / 1 ReLU, 6 ReLU6"""
+    return 6 if (relu == 6 and relu is not True) else int(bool(relu))
+
+
 def bn_apply(y, coef, relu, residual=None, out=None):
     m, c, ldy = rows(y)
     if out is None:
@@ -364,7 +369,7 @@ def bn_apply(y, coef, relu, residual=None, out=None):
     if residual is not None:
         mr, cr, ldr = rows(residual)
         assert (mr, cr) == (m, c)
-    call("iswm_bn_apply", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(residual), ldr, int(bool(relu)), _p(out),
+    call("iswm_bn_apply", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(residual), ldr, _relu_code(relu), _p(out),
          ldo, _stream())
     return out
 
@@ -384,10 +389,10 @@ def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_d
     dres = torch.empty(y.shape, dtype=torch.float32, device=y.device) if want_dres else None
     # ReLU without a residual: hand over the forward's scale / shift so the sign pattern is recomputed from y and the
     # saved output is never read (a residual stage's pattern depends on the identity tensor: read `out` there)
-    masky = bool(relu) and not want_dres and _BN_MASK_FROM_Y
+    masky = _relu_code(relu) == 1 and not want_dres and _BN_MASK_FROM_Y
     call("iswm_bn_backward", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
          _p(coef[0]) if masky else None, _p(coef[1]) if masky else None,
-         int(bool(relu)), int(bool(training)), _p(dgamma), _p(dbeta), _p(dy), rows(dy)[2], _p(dres),
+         _relu_code(relu), int(bool(training)), _p(dgamma), _p(dbeta), _p(dy), rows(dy)[2], _p(dres),
          rows(dres)[2] if dres is not None else 0, _p(ws), need, _stream())
     return dy, dres
 

@@ -173,7 +173,7 @@ def test_conv_pitched_slices_and_bias(conv_math):
 
 @pytest.mark.parametrize("c,m_shape", [(64, (2, 17, 19)), (48, (2, 9, 9)), (256, (4, 1, 1)), (304, (1, 13, 11)),
                                        (2048, (2, 5, 5)), (4, (2, 33, 33))])
-@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (6, False), (6, True)])
 def test_batchnorm_train_fwd_bwd(c, m_shape, relu, res):
     from iswm_amd import ops
     n, h, w = m_shape
@@ -188,7 +188,9 @@ def test_batchnorm_train_fwd_bwd(c, m_shape, relu, res):
     o_ref = F.batch_norm(yr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
     if res:
         o_ref = o_ref + rr
-    if relu:
+    if relu == 6 and relu is not True:
+        o_ref = F.relu6(o_ref)                                # nn.ReLU6: clamp to [0, 6]
+    elif relu:
         o_ref = F.relu(o_ref)
     dout = rnd(n, c, h, w, seed=13)
     o_ref.backward(dout)

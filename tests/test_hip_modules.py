@@ -677,3 +677,33 @@ def test_bf16_mixed_precision_mode():
         assert abs(losses[2] - losses[0]) < 3e-2 * abs(losses[0]), losses
     finally:
         lib.iswm_set_conv_math(old)
+
+
+def test_depthwise_bn_relu6_stage():
+    """nn.Conv2d(groups=C) -> BatchNorm2d -> ReLU6 (the stage MobileNetV2-style backbones are made of) through the fused
+    stage logic: statistics from a column pass, clamp fused into the BatchNorm pass; vs torch on the CPU"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from iswm_amd.network import _hip
+    torch.manual_seed(3)
+    c = 48
+    seq = _hip.HipSequential(_hip.DepthwiseConv2d(c, c, 3, stride=2, padding=1, groups=c, bias=False),
+                             _hip.BatchNorm2d(c), _hip.ReLU6(inplace=True))
+    ref = nn.Sequential(nn.Conv2d(c, c, 3, stride=2, padding=1, groups=c, bias=False), nn.BatchNorm2d(c), nn.ReLU6())
+    with torch.no_grad():
+        seq[1].weight.fill_(4.0)                   # normalised values x 4: the clamp at 6 is exercised on both sides
+    ref.load_state_dict(seq.state_dict())
+    seq = seq.to(dev()).train()
+    ref.train()
+    x = torch.randn(4, c, 21, 17) * 2
+    xg, xr = x.to(dev()).requires_grad_(True), x.clone().requires_grad_(True)
+    y, yr = seq(xg), ref(xr)
+    assert float((yr == 6).float().mean()) > 0.01 and float((yr == 0).float().mean()) > 0.05
+    assert rel_err(y, yr.detach()) <= 1e-5
+    up = torch.randn(yr.shape)
+    y.backward(up.to(dev()))
+    yr.backward(up)
+    assert rel_err(xg.grad, xr.grad) <= 2e-4
+    for (k, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) <= 2e-4, k
+    assert rel_err(seq[1].running_var, ref[1].running_var) <= 1e-5
