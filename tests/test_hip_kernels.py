@@ -433,3 +433,57 @@ def test_layout_roundtrip_and_copy():
     cat = torch.zeros(2, 5, 5, 304, device=dev())
     ops.copy_channels(a, cat[..., 256:])
     assert torch.equal(cat[..., 256:], a)
+
+
+def _fuzz_cases(count, seed):
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < count:
+        k = rng.choice([1, 1, 3, 3, 3, 5])
+        s = rng.choice([1, 1, 1, 2])
+        d = 1 if k == 1 else rng.choice([1, 1, 2, 3, 6])
+        p = rng.choice([0, d * (k // 2), d * (k // 2), 1]) if k > 1 else 0
+        cin = rng.choice([4, 8, 32, 32, 64, 96, 128, 160, 256, 320])
+        cout = rng.choice([4, 8, 24, 32, 48, 64, 96, 128, 192, 256])
+        h, w = rng.randint(1, 47), rng.randint(1, 47)
+        n = rng.randint(1, 5)
+        if (h + 2 * p - d * (k - 1) - 1) // s + 1 < 1 or (w + 2 * p - d * (k - 1) - 1) // s + 1 < 1:
+            continue
+        if n * h * w * cin * k * k > 6_000_000:
+            continue
+        cases.append((cin, cout, k, s, p, d, h, w, n))
+    return cases
+
+
+@pytest.mark.parametrize("conv_math", [0, 1], indirect=True, ids=["f32mfma", "bf16x6"])
+def test_conv_geometry_fuzz(conv_math):
+    """60 seeded random geometries (odd / tiny maps down to 1x1, 5x5 filters, padding smaller or larger than 'same',
+    channel counts on both sides of the 32 / 64 tile edges, batch 1..5) through forward, data gradient (plain and
+    accumulating) and weight gradient: every tile picker / patch planner / parity / culling branch the fixed cases may
+    miss, vs torch fp32 on the CPU"""
+    from iswm_amd import ops
+    for case in _fuzz_cases(60, 20261004):
+        cin, cout, k, s, p, d, h, w, n = case
+        x = rnd(n, cin, h, w, seed=1)
+        wt = rnd(cout, cin, k, k, seed=2) * (2.0 / (cin * k * k)) ** 0.5
+        xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        y_ref = F.conv2d(xr, wr, None, s, p, d)
+        dy = rnd(*y_ref.shape, seed=3)
+        y_ref.backward(dy)
+        xh = nhwc(x)
+        w_ohwi = wt.permute(0, 2, 3, 1).contiguous().to(dev())
+        g = ops.ConvGeom(xh, cout, k, k, s, p, d)
+        y, partials, tiles = ops.conv2d_fwd(xh, w_ohwi, g, want_stats=True)
+        assert rel_err(nchw(y), y_ref) < 2e-5, case
+        count = n * g.ho * g.wo
+        coef = ops.bn_finalize(partials, tiles[0], count, tiles[1], None, None, None, None, 0.1)
+        assert rel_err(coef[2], y_ref.detach().double().mean((0, 2, 3))) < 1e-5, case
+        dyh = nhwc(dy)
+        dx = ops.conv2d_dgrad(dyh, w_ohwi, g, tuple(xh.shape))
+        scale = max(float(xr.grad.abs().max()), 1e-30)
+        assert float((nchw(dx) - xr.grad).abs().max()) <= 2e-5 * scale + 1e-12, case
+        dx2 = ops.conv2d_dgrad(dyh, w_ohwi, g, tuple(xh.shape), dx=dx.clone(), accumulate=True)
+        assert float((nchw(dx2) - 2 * xr.grad).abs().max()) <= 4e-5 * scale + 1e-12, case
+        dw = ops.conv2d_wgrad(xh, dyh, g)
+        assert rel_err(dw.cpu().permute(0, 3, 1, 2), wr.grad) < 5e-5, case

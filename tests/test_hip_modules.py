@@ -707,3 +707,30 @@ def test_depthwise_bn_relu6_stage():
     for (k, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad, q.grad) <= 2e-4, k
     assert rel_err(seq[1].running_var, ref[1].running_var) <= 1e-5
+
+
+@pytest.mark.parametrize("os_,n,h,w", [(16, 3, 97, 131), (8, 2, 73, 49), (16, 2, 33, 200)])
+def test_whole_model_odd_sizes(os_, n, h, w):
+    """non-square / odd input sizes and batch 3 (nothing in the path assumes 65 or 513): logits in eval and train mode and
+    the loss vs the CPU oracle"""
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle import loss as oloss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.synth import synth_images, synth_labels
+    m, cfg, sd = _build("resnet50", os_)
+    x = synth_images(n, h, w, seed=51)
+    lab = synth_labels(n, h, w, seed=51, p_fg=0.2, p_ignore=0.05)
+    o = OracleDeepLab(cfg, sd, dropout_p=0.0)
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(x.to(dev())), o.eval()(x)) <= RTOL
+    m.train()
+    lg = m(x.to(dev()))
+    with torch.no_grad():
+        lo = o.train()(x)
+    assert lg.shape == (n, 2, h, w) and rel_err(lg, lo) <= RTOL
+    wgt = torch.tensor([1.0, 3.0])
+    loss = CrossEntropyLoss(weight=wgt, ignore_index=255)(lg, lab.to(dev()))
+    assert rel_err(loss, oloss.weighted_ce(lo, lab, wgt, 255)) <= RTOL
+    loss.backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
