@@ -63,7 +63,13 @@ class _SimpleSegmentationModel(nn.Module):
         if self.training:
             flat = self._counters()
             if flat is not None:
-                flat.add_(1)
+                bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+                if all(b.training for b in bns):
+                    flat.add_(1)                               # one op for every num_batches_tracked
+                else:                                          # utils.fix_bn etc.: only layers in training mode count
+                    for b in bns:
+                        if b.training and b.num_batches_tracked is not None:
+                            b.num_batches_tracked.add_(1)
         pk = self._packer()
         pk.begin()                                             # all conv weights -> bf16x6 fragments, one launch
         try:

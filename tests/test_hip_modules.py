@@ -734,3 +734,39 @@ def test_whole_model_odd_sizes(os_, n, h, w):
     assert rel_err(loss, oloss.weighted_ce(lo, lab, wgt, 255)) <= RTOL
     loss.backward()
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_fix_bn_training_step():
+    """utils.fix_bn (utils/utils.py:30-33): BatchNorm layers frozen in eval mode while the model trains -- the fused
+    stage normalises with the running statistics, leaves them untouched, and its backward is the eval-mode one.  Logits,
+    loss and every gradient vs the oracle evaluated the same way (its eval mode, dropout off)."""
+    from iswm_amd.utils import fix_bn
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle import loss as oloss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.synth import synth_images, synth_labels
+    m, cfg, sd = _build("resnet50", 16)
+    m.train()
+    fix_bn(m)
+    x = synth_images(4, 65, 65, seed=61)
+    lab = synth_labels(4, 65, 65, seed=61, p_fg=0.2)
+    with record_masks(m, "") as rec:
+        lg = m(x.to(dev()))
+    for p in m.parameters():
+        p.grad = None
+    up = upstream(lg.shape, 15)
+    lg.backward(up.to(dev()))
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k]), k                # frozen statistics
+    o = OracleDeepLab(cfg, sd, dropout_p=0.0).eval()
+    o.relu_masks, o.preact = rec.masks(), {}
+    lgo = o(x)
+    assert rel_err(lg, lgo.detach()) <= RTOL
+    w = torch.tensor([1.0, 3.0])
+    assert rel_err(CrossEntropyLoss(weight=w)(lg, lab.to(dev())), oloss.weighted_ce(lgo.detach(), lab, w)) <= RTOL
+    lgo.backward(up)
+    check_sign_patterns(o, o.relu_masks)
+    params = dict(m.named_parameters())
+    worst = max((rel_err(params[k].grad, v.grad), k) for k, v in o.named_parameters())
+    assert worst[0] <= 3 * RTOL, worst

@@ -186,3 +186,51 @@ def test_c_abi_argument_validation_without_a_gpu():
         assert lib.iswm_conv2d_packed_weight_bytes(ctypes.byref(d), 0) == 0         # exact-fp32 path: no packed form
     finally:
         lib.iswm_set_conv_math(old)
+
+
+def test_poly_lr_matches_reference_scheduler():
+    """utils/scheduler.py:3-11 (importable standalone) vs iswm_amd.utils.PolyLR on the fused optimizer's host side"""
+    import importlib.util
+    ref_path = "/root/reference/utils/scheduler.py"
+    from iswm_amd.utils import PolyLR
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9)
+    sch = PolyLR(opt, max_iters=50, power=0.9)
+    got = []
+    for _ in range(50):                          # (past max_iters the reference's formula leaves the reals; so does this)
+        opt.step()
+        sch.step()
+        got.append(opt.param_groups[0]["lr"])
+    want = [max(0.01 * (1 - t / 50) ** 0.9, 1e-6) for t in range(1, 51)]
+    for t, (g, w) in enumerate(zip(got, want)):
+        assert abs(g - w) <= 1e-12, (t, g, w)
+    assert got[-1] == 1e-6                       # min_lr floor at the last iteration
+    if os.path.exists(ref_path):                 # in the build container: the reference's own class, step for step
+        spec = importlib.util.spec_from_file_location("ref_sched", ref_path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        q = torch.nn.Parameter(torch.zeros(3))
+        opt2 = torch.optim.SGD([q], lr=0.01, momentum=0.9)
+        sch2 = mod.PolyLR(opt2, max_iters=50, power=0.9)
+        for t in range(45):
+            opt2.step()
+            sch2.step()
+            assert opt2.param_groups[0]["lr"] == got[t]
+
+
+def test_small_utils():
+    """utils/utils.py:6-38: denormalize undoes ExtNormalize; set_bn_momentum / fix_bn touch every BatchNorm2d"""
+    import numpy as np
+    from iswm_amd.network import modeling
+    from iswm_amd.utils import Denormalize, denormalize, fix_bn, set_bn_momentum
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    img = torch.rand(3, 5, 7)
+    norm = (img - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+    assert torch.allclose(denormalize(norm, mean, std), img, atol=1e-6)
+    assert torch.allclose(Denormalize(mean, std)(norm), img, atol=1e-6)
+    assert np.allclose(Denormalize(mean, std)(norm.numpy()), img.numpy(), atol=1e-6)
+    m = modeling.deeplabv3plus_resnet50(num_classes=2, output_stride=16).train()
+    set_bn_momentum(m, 0.01)
+    fix_bn(m)
+    bns = [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d)]
+    assert len(bns) == 62 and all(b.momentum == 0.01 and not b.training for b in bns) and m.training
