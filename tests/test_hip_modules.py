@@ -770,3 +770,51 @@ def test_fix_bn_training_step():
     params = dict(m.named_parameters())
     worst = max((rel_err(params[k].grad, v.grad), k) for k, v in o.named_parameters())
     assert worst[0] <= 3 * RTOL, worst
+
+
+def test_autograd_semantics_accumulation_and_frozen_parameters():
+    """what the reference's training scripts may rely on from torch.autograd: a second backward without zero_grad()
+    ACCUMULATES into .grad; parameters with requires_grad=False get no gradient and do not change the others';
+    set_to_none=False zero_grad keeps the same gradient tensors."""
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle.synth import synth_images, synth_labels
+    m, cfg, sd = _build("resnet50", 16)
+    m.train()
+    crit = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]))
+    xa, xb = synth_images(4, 65, 65, seed=81).to(dev()), synth_images(4, 65, 65, seed=82).to(dev())
+    la, lb = synth_labels(4, 65, 65, seed=81).to(dev()), synth_labels(4, 65, 65, seed=82).to(dev())
+
+    def grads_of(x, lab):
+        m.load_state_dict(sd, strict=True)
+        for p in m.parameters():
+            p.grad = None
+        crit(m(x), lab).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    ga, gb = grads_of(xa, la), grads_of(xb, lb)
+    m.load_state_dict(sd, strict=True)
+    for p in m.parameters():
+        p.grad = None
+    crit(m(xa), la).backward()
+    crit(m(xb), lb).backward()                                   # no zero_grad in between
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, ga[k] + gb[k]) <= 1e-6, k
+    held = {k: p.grad for k, p in m.named_parameters()}
+    for p in m.parameters():                                     # zero_grad(set_to_none=False)
+        p.grad.zero_()
+    crit(m(xa), la).backward()
+    for k, p in m.named_parameters():
+        assert p.grad is held[k] and rel_err(p.grad, ga[k]) <= 1e-6, k
+    # frozen backbone
+    m.load_state_dict(sd, strict=True)
+    for p in m.parameters():
+        p.grad = None
+    for p in m.backbone.parameters():
+        p.requires_grad_(False)
+    crit(m(xa), la).backward()
+    for k, p in m.named_parameters():
+        if k.startswith("backbone."):
+            assert p.grad is None, k
+        else:
+            assert torch.equal(p.grad, ga[k]), k
+    for p in m.backbone.parameters():
+        p.requires_grad_(True)
