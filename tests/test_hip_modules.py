@@ -818,3 +818,51 @@ def test_autograd_semantics_accumulation_and_frozen_parameters():
             assert torch.equal(p.grad, ga[k]), k
     for p in m.backbone.parameters():
         p.requires_grad_(True)
+
+
+def test_num_classes_21_and_batch_one():
+    """a 21-class head (the reference constructors' default num_classes, network/modeling.py:75) -- classifier padded to 24
+    channels, loss over 21 classes -- vs the oracle; eval-mode batch 1; training batch 1 raises like torch (the ASPP
+    image-pooling BatchNorm sees one value per channel, network/_deeplab.py:130-141)."""
+    from iswm_amd.network import modeling
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle import loss as oloss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.synth import ArchCfg, synth_images, synth_state_dict
+    cfg = ArchCfg("deeplabv3plus", "resnet50", 21, 16)
+    sd = synth_state_dict(cfg)
+    m = modeling.deeplabv3plus_resnet50(num_classes=21, output_stride=16, pretrained_backbone=False)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m.classifier.aspp.project[3].p = 0.0
+    m = m.to(dev()).train()
+    x = synth_images(4, 65, 65, seed=91)
+    g = torch.Generator().manual_seed(92)
+    lab = torch.randint(0, 21, (4, 65, 65), generator=g)
+    lab[torch.rand(4, 65, 65, generator=g) < 0.05] = 255
+    w = torch.linspace(0.5, 2.5, 21)
+    with record_masks(m, "") as rec:
+        lg = m(x.to(dev()))
+    o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
+    o.relu_masks, o.preact = rec.masks(), {}
+    lgo = o(x)
+    assert lg.shape == (4, 21, 65, 65) and rel_err(lg, lgo.detach()) <= RTOL
+    loss = CrossEntropyLoss(weight=w, ignore_index=255)(lg, lab.to(dev()))
+    lo = oloss.weighted_ce(lgo, lab, w, 255)
+    assert rel_err(loss, lo.detach()) <= RTOL
+    for p in m.parameters():
+        p.grad = None
+    up = upstream(lg.shape, 16)
+    lg.backward(up.to(dev()))
+    lgo.backward(up)
+    params = dict(m.named_parameters())
+    for k in ("classifier.classifier.6.weight", "classifier.classifier.6.bias", "classifier.classifier.3.weight"):
+        assert rel_err(params[k].grad, o.sd[k].grad) <= 3 * RTOL, k
+    m.load_state_dict(sd, strict=True)                           # (the training forward moved the running statistics)
+    m.eval()
+    with torch.no_grad():
+        one = m(x[:1].to(dev()))
+        assert rel_err(one, OracleDeepLab(cfg, sd, dropout_p=0.0).eval()(x[:1])) <= RTOL
+    m.train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        m(x[:1].to(dev()))
