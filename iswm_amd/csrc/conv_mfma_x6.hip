@@ -24,35 +24,6 @@ static __device__ __attribute__((aligned(16))) float g_zero_row_x[64];
 
 constexpr int X6_PITCH = 80;   // bytes per LDS row of one bf16 plane (32 k x 2 B + 16 B pad)
 
-// GEMM row m -> pixel (n, rh, rw) of an N x RH x RW grid.  par == false: row-major.  par == true (data gradient of
-// a stride-2 conv): rows are grouped by the PARITY class (rh & 1, rw & 1) of the pixel -- classes (0,0), (0,1),
-// (1,0), (1,1), each row-major over (n, rh >> 1, rw >> 1) -- because a tap (kh, kw) only reaches input pixels of one
-// parity class: with uniform-parity tiles the per-tile tap culling drops the 3/4 (1x1) or ~5/9..8/9 (3x3) of the taps
-// that would gather nothing but zeros.
-__device__ __forceinline__ void x6_row_pixel(int m, int N, int RH, int RW, bool par, int& n, int& rh, int& rw) {
-    if (!par) {
-        const int RHW = RH * RW;
-        n = m / RHW;
-        const int rem = m - n * RHW;
-        rh = rem / RW;
-        rw = rem - rh * RW;
-        return;
-    }
-    const int H0 = (RH + 1) >> 1, H1 = RH >> 1, W0 = (RW + 1) >> 1, W1 = RW >> 1;
-    const int o1 = N * H0 * W0, o2 = o1 + N * H0 * W1, o3 = o2 + N * H1 * W0;
-    int ph, pw, r;
-    if (m < o1) { ph = 0; pw = 0; r = m; }
-    else if (m < o2) { ph = 0; pw = 1; r = m - o1; }
-    else if (m < o3) { ph = 1; pw = 0; r = m - o2; }
-    else { ph = 1; pw = 1; r = m - o3; }
-    const int Hc = ph ? H1 : H0, Wc = pw ? W1 : W0, S = Hc * Wc;
-    n = r / S;
-    const int rem = r - n * S;
-    const int i = rem / Wc;
-    rh = 2 * i + ph;
-    rw = 2 * (rem - i * Wc) + pw;
-}
-
 // DGRAD == false: forward.  rows = output pixels, A = x gathered per tap, B = OHWI weights [cout][(tap, cin)].
 // DGRAD == true : data gradient.  rows = INPUT pixels, A = dy gathered per tap (a.x = dy, pitch a.ldx),
 //                 B = TRANSPOSED weights [cin][(tap, cout)] (iswm_transpose_weights), output a.y = dx.
