@@ -76,6 +76,8 @@ def get_argparser():
                         choices=['spatial', 'temporal_p1', 'temporal_p2', 'temporal_p3', 'temporal_p4'])
     # additions
     parser.add_argument("--synthetic_len", type=int, default=256, help="tiles in the synthetic train split")
+    parser.add_argument("--num_workers", type=int, default=2,
+                        help="DataLoader worker processes of the train loader (the reference hard-codes 4, train.py:950)")
     parser.add_argument("--device_augment", action='store_true', default=False,
                         help="run the reference's train_transform (random scale / crop / flip / normalise, "
                              "train.py:355-362) as one HIP kernel per batch on uint8 tiles")
@@ -225,7 +227,7 @@ def main(argv=None):
             et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]),
         ])
     train_loader = data.DataLoader(train_dst, batch_size=opts.batch_size, shuffle=sampler is None, sampler=sampler,
-                                   num_workers=2, drop_last=True)
+                                   num_workers=opts.num_workers, drop_last=True)
     val_loader = data.DataLoader(val_dst, batch_size=opts.val_batch_size, shuffle=False, num_workers=0)
     class_weights = calculate_class_weights(train_loader).to(device)
     if rank == 0:

@@ -16,7 +16,7 @@ def test_train_validate_checkpoint_resume(tmp_path, capsys):
     ck = str(tmp_path / "ck")
     base = ["--model", "deeplabv3plus_resnet50", "--crop_size", "65", "--batch_size", "4", "--synthetic_len", "16",
             "--optimizer", "sgd", "--loss_type", "IWce_loss", "--print_interval", "2", "--val_interval", "2",
-            "--val_batch_size", "4", "--checkpoints_dir", ck]
+            "--val_batch_size", "4", "--checkpoints_dir", ck, "--num_workers", "0"]
     train.main(base + ["--total_itrs", "4"])
     out = capsys.readouterr().out
     assert "Itrs 4/4" in out and "Validation @2" in out
@@ -39,7 +39,7 @@ def test_train_with_device_augmentation(tmp_path, capsys):
     train.main(["--model", "deeplabv3plus_resnet50", "--crop_size", "65", "--batch_size", "4", "--synthetic_len", "16",
                 "--optimizer", "sgd", "--loss_type", "IWce_loss", "--print_interval", "2", "--val_interval", "3",
                 "--val_batch_size", "4", "--checkpoints_dir", str(tmp_path / "ck"), "--total_itrs", "3",
-                "--device_augment"])
+                "--device_augment", "--num_workers", "2"])
     out = capsys.readouterr().out
     assert "Itrs 2/3" in out and "Validation @3" in out and "MIoU" in out
 
@@ -52,7 +52,7 @@ def test_train_other_optimizers_and_losses_resume(tmp_path, capsys, optimizer, l
     ck = str(tmp_path / "ck")
     base = ["--model", "deeplabv3plus_resnet50", "--crop_size", "65", "--batch_size", "4", "--synthetic_len", "16",
             "--optimizer", optimizer, "--loss_type", loss_type, "--print_interval", "2", "--val_interval", "2",
-            "--val_batch_size", "4", "--checkpoints_dir", ck]
+            "--val_batch_size", "4", "--checkpoints_dir", ck, "--num_workers", "0"]
     train.main(base + ["--total_itrs", "2"])
     out = capsys.readouterr().out
     assert "Itrs 2/2" in out and "Validation @2" in out
