@@ -487,3 +487,18 @@ def test_conv_geometry_fuzz(conv_math):
         assert float((nchw(dx2) - 2 * xr.grad).abs().max()) <= 4e-5 * scale + 1e-12, case
         dw = ops.conv2d_wgrad(xh, dyh, g)
         assert rel_err(dw.cpu().permute(0, 3, 1, 2), wr.grad) < 5e-5, case
+
+
+def test_loss_all_pixels_ignored_matches_torch():
+    """every label == ignore_index: nn.CrossEntropyLoss(reduction='mean') divides 0 by 0 -> nan (value and gradient
+    of zeros * nan); FocalLoss (mean over ALL pixels, utils/loss.py:23-35) gives 0 with a zero gradient"""
+    from iswm_amd.utils.loss import CrossEntropyLoss, FocalLoss
+    lg = rnd(2, 2, 9, 7, seed=4)
+    lab = torch.full((2, 9, 7), 255, dtype=torch.int64)
+    ref = F.cross_entropy(lg, lab, weight=torch.tensor([1.0, 3.0]), ignore_index=255)
+    got = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]), ignore_index=255)(lg.to(dev()), lab.to(dev()))
+    assert bool(torch.isnan(ref)) and bool(torch.isnan(got.cpu()))
+    x = lg.to(dev()).requires_grad_(True)
+    f = FocalLoss(alpha=0.25, gamma=2.0, ignore_index=255)(x, lab.to(dev()))
+    f.backward()
+    assert float(f.detach()) == 0.0 and float(x.grad.abs().max()) == 0.0
