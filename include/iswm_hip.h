@@ -113,6 +113,26 @@ int iswm_conv2d_fwd_packed(const iswm_conv_desc* d, const float* x, const void* 
                            float* y, float* stat_partials, iswm_stream_t stream);
 int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy, const void* wpk, float* dx, int accumulate,
                              iswm_stream_t stream);
+/* ---- "planes": activations stored PRE-SPLIT for the bf16x6 kernels.  A planes tensor is three bf16 tensors
+ * [plane][pixel][ld] (hi, mid, lo -- the exact truncation split, hi + mid + lo == the fp32 value), plane_stride
+ * bf16 elements apart (one plane under conv math "bf16": the value rounded to nearest).  The producer of an
+ * activation writes the split once; the convolution stages its activation operand HBM -> LDS by LDS-DMA with no
+ * split arithmetic in the loop.  In the *_planes entry points the pitch of the planes operand (d->ldx forward,
+ * d->ldy data gradient) counts bf16 elements and must be a multiple of 8; same call sites as iswm_conv2d_fwd. */
+int iswm_split_planes(const float* x, int64_t M, int C, int ldx, void* planes, int ldp, int64_t plane_stride,
+                      iswm_stream_t stream);
+int iswm_conv2d_fwd_planes(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
+                           const float* bias, float* y, float* stat_partials, iswm_stream_t stream);
+int iswm_conv2d_dgrad_planes(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
+                             float* dx, int accumulate, iswm_stream_t stream);
+/* second-generation planes kernels: (16*rbw) x 128 tiles, weights packed for the 16x16x32 MFMA (own packing) */
+size_t iswm_conv2d_pl2_weight_bytes(const iswm_conv_desc* d, int kind);
+int iswm_conv2d_pl2_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed, iswm_stream_t stream);
+int iswm_conv2d_pl2_tile_rows(const iswm_conv_desc* d, int kind);
+int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
+                        const float* bias, float* y, float* stat_partials, iswm_stream_t stream);
+int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
+                          float* dx, int accumulate, iswm_stream_t stream);
 /* ---- depthwise convolution (groups == channels): first half of AtrousSeparableConvolution,
  * network/_deeplab.py:95-119.  The descriptor has Cin == Cout == channel count of the (possibly zero-padded)
  * activation; w is the torch parameter [Cw][1][KH][KW] as stored, Cw <= Cin (extra channels see zero weights).

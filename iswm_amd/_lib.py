@@ -41,6 +41,14 @@ _SIGS = {
     "iswm_conv2d_fwd_packed_stat_layout": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
     "iswm_conv2d_fwd_packed": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "iswm_conv2d_dgrad_packed": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
+    "iswm_split_planes": (c_int, [P, c_int64, c_int, c_int, P, c_int, c_int64, P]),
+    "iswm_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, P, P, P]),
+    "iswm_conv2d_dgrad_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P]),
+    "iswm_conv2d_pl2_weight_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "iswm_conv2d_pl2_pack_weights": (c_int, [POINTER(ConvDesc), c_int, P, P, P]),
+    "iswm_conv2d_pl2_tile_rows": (c_int, [POINTER(ConvDesc), c_int]),
+    "iswm_conv2d_fwd_pl2": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, P, P, P]),
+    "iswm_conv2d_dgrad_pl2": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P]),
     "iswm_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "iswm_dwconv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "iswm_dwconv2d_dgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, c_int, P]),

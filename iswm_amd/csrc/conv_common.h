@@ -20,6 +20,7 @@ struct ConvArgs {
     int nsplit;  // wgrad: K splits
     int psplit;  // wgrad: pixels per split (multiple of 32)
     int accumulate;  // dgrad: dx += result instead of dx = result
+    long long xps;   // plane kernels (conv_mfma_pl.hip): byte stride between the bf16 planes of the gathered operand
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -110,6 +111,17 @@ void launch_pack_weights_batch(const void* jobs_dev, int njobs, int total_blocks
 int pack_job_blocks_x6(int Cout, int T, int Cin, bool dgrad);
 void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s);
 void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s);
+
+// pre-split ("planes") activations, LDS-DMA staged (conv_mfma_pl.hip)
+bool launch_conv_pl(ConvArgs a, hipStream_t s, bool dgrad, int bm, int planes);
+void launch_split_planes(const float* x, int64_t M, int C, int ldx, unsigned short* out, int ldp, int64_t pstride_elems,
+                         int planes, hipStream_t s);
+
+// second-generation planes kernel: (16*rbw) x 128 tiles, one workgroup per CU (conv_mfma_pl2.hip)
+int conv_pl2_pick_rbw(int64_t M, int cols);
+bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw);
+size_t packed_weight_bytes_pl2(int Cout, int T, int Cin, bool dgrad, int planes);
+void launch_pack_weights_pl2(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s);
 
 // halo-patch bf16x6 kernel for stride-1 KxK filters (conv_mfma_x6p.hip)
 struct PatchArgs {

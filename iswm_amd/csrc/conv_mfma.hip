@@ -1052,6 +1052,108 @@ extern "C" int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy
     return check_launch("conv_dgrad_packed");
 }
 
+/* ---- activations pre-split into bf16 planes (see include/iswm_hip.h "planes") ---- */
+extern "C" int iswm_split_planes(const float* x, int64_t M, int C, int ldx, void* planes, int ldp, int64_t plane_stride,
+                                 iswm_stream_t stream) {
+    ISWM_REQUIRE(x && planes && M > 0 && C > 0, "split_planes: bad argument");
+    ISWM_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldx >= C && ldp % 8 == 0 && ldp >= C, "split_planes: C %d ldx %d ldp %d", C, ldx, ldp);
+    ISWM_REQUIRE(aligned16(x) && aligned16(planes) && plane_stride % 8 == 0 && plane_stride >= M * ldp,
+                 "split_planes: planes must be 16-byte aligned and disjoint");
+    launch_split_planes(x, M, C, ldx, (unsigned short*)planes, ldp, plane_stride, math_planes(), (hipStream_t)stream);
+    return check_launch("split_planes");
+}
+
+extern "C" int iswm_conv2d_fwd_planes(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
+                                      const float* bias, float* y, float* stat_partials, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(xp && wpk && y, "conv_fwd_planes: null pointer");
+    ISWM_REQUIRE(aligned16(xp) && aligned16(wpk) && aligned16(y), "conv_fwd_planes: pointers must be 16-byte aligned");
+    ISWM_REQUIRE(d->Cin % 32 == 0 && d->ldx % 8 == 0 && plane_stride % 8 == 0, "conv_fwd_planes: Cin %% 32, ldx %% 8, plane stride %% 8");
+    ConvArgs a = base_args(d);
+    a.x = reinterpret_cast<const float*>(xp); a.w = reinterpret_cast<const float*>(wpk); a.bias = bias; a.y = y;
+    a.stats = stat_partials;
+    a.xps = plane_stride * 2;
+    a.M = d->N * d->Ho * d->Wo;
+    a.Ktot = d->KH * d->KW * d->Cin;
+    int bm, bn;
+    conv_pick_tile_x6(a.M, d->Cout, a.Ktot, false, d->KH * d->KW == 1, &bm, &bn);
+    launch_conv_pl(a, (hipStream_t)stream, false, bm, math_planes());
+    return check_launch("conv_fwd_planes");
+}
+
+extern "C" int iswm_conv2d_dgrad_planes(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
+                                        float* dx, int accumulate, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(dyp && wpk && dx, "conv_dgrad_planes: null pointer");
+    ISWM_REQUIRE(aligned16(dyp) && aligned16(wpk) && aligned16(dx), "conv_dgrad_planes: pointers must be 16-byte aligned");
+    ISWM_REQUIRE(d->Cout % 32 == 0 && d->ldy % 8 == 0 && plane_stride % 8 == 0, "conv_dgrad_planes: Cout %% 32, ldy %% 8, plane stride %% 8");
+    ConvArgs a = base_args(d);
+    a.x = reinterpret_cast<const float*>(dyp); a.w = reinterpret_cast<const float*>(wpk); a.y = dx; a.accumulate = accumulate;
+    a.ldx = d->ldy; a.ldy = d->ldx;
+    a.xps = plane_stride * 2;
+    a.M = d->N * d->H * d->W;
+    a.Ktot = d->KH * d->KW * d->Cout;
+    int bm, bn;
+    conv_pick_tile_x6(a.M, d->Cin, a.Ktot, true, d->KH * d->KW == 1, &bm, &bn);
+    launch_conv_pl(a, (hipStream_t)stream, true, bm, math_planes());
+    return check_launch("conv_dgrad_planes");
+}
+
+/* second-generation planes kernels (conv_mfma_pl2.hip): kind 0 forward, 1 data gradient */
+extern "C" size_t iswm_conv2d_pl2_weight_bytes(const iswm_conv_desc* d, int kind) {
+    if (!d || conv_math() < 1 || (kind != 0 && kind != 1)) return 0;
+    const int gc = kind ? d->Cout : d->Cin;
+    if (gc % 64 != 0) return 0;
+    return packed_weight_bytes_pl2(d->Cout, d->KH * d->KW, d->Cin, kind == 1, math_planes());
+}
+
+extern "C" int iswm_conv2d_pl2_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed,
+                                            iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(kind == 0 || kind == 1, "pl2_pack_weights: kind must be 0 (forward) or 1 (data gradient)");
+    ISWM_REQUIRE(w && packed && aligned16(packed), "pl2_pack_weights: bad pointer");
+    ISWM_REQUIRE((kind ? d->Cout : d->Cin) % 64 == 0, "pl2_pack_weights: gathered channel count must be a multiple of 64");
+    launch_pack_weights_pl2(w, packed, d->Cout, d->KH * d->KW, d->Cin, kind == 1, math_planes(), (hipStream_t)stream);
+    return check_launch("pl2_pack_weights");
+}
+
+extern "C" int iswm_conv2d_pl2_tile_rows(const iswm_conv_desc* d, int kind) {
+    if (!d) return 0;
+    return 16 * (kind ? conv_pl2_pick_rbw((int64_t)d->N * d->H * d->W, d->Cin) : conv_pl2_pick_rbw((int64_t)d->N * d->Ho * d->Wo, d->Cout));
+}
+
+extern "C" int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
+                                   const float* bias, float* y, float* stat_partials, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(xp && wpk && y, "conv_fwd_pl2: null pointer");
+    ISWM_REQUIRE(aligned16(xp) && aligned16(wpk) && aligned16(y), "conv_fwd_pl2: pointers must be 16-byte aligned");
+    ISWM_REQUIRE(d->Cin % 64 == 0 && d->ldx % 8 == 0 && plane_stride % 8 == 0, "conv_fwd_pl2: Cin %% 64, ldx %% 8, plane stride %% 8");
+    ConvArgs a = base_args(d);
+    a.x = reinterpret_cast<const float*>(xp); a.w = reinterpret_cast<const float*>(wpk); a.bias = bias; a.y = y;
+    a.stats = stat_partials;
+    a.xps = plane_stride * 2;
+    a.M = d->N * d->Ho * d->Wo;
+    a.Ktot = d->KH * d->KW * d->Cin;
+    ISWM_REQUIRE(launch_conv_pl2(a, (hipStream_t)stream, false, math_planes(), conv_pl2_pick_rbw(a.M, d->Cout)), "conv_fwd_pl2: no kernel for this configuration");
+    return check_launch("conv_fwd_pl2");
+}
+
+extern "C" int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
+                                     float* dx, int accumulate, iswm_stream_t stream) {
+    if (int e = validate(d)) return e;
+    ISWM_REQUIRE(dyp && wpk && dx, "conv_dgrad_pl2: null pointer");
+    ISWM_REQUIRE(aligned16(dyp) && aligned16(wpk) && aligned16(dx), "conv_dgrad_pl2: pointers must be 16-byte aligned");
+    ISWM_REQUIRE(d->Cout % 64 == 0 && d->ldy % 8 == 0 && plane_stride % 8 == 0, "conv_dgrad_pl2: Cout %% 64, ldy %% 8, plane stride %% 8");
+    ConvArgs a = base_args(d);
+    a.x = reinterpret_cast<const float*>(dyp); a.w = reinterpret_cast<const float*>(wpk); a.y = dx; a.accumulate = accumulate;
+    a.ldx = d->ldy; a.ldy = d->ldx;
+    a.xps = plane_stride * 2;
+    a.M = d->N * d->H * d->W;
+    a.Ktot = d->KH * d->KW * d->Cout;
+    ISWM_REQUIRE(launch_conv_pl2(a, (hipStream_t)stream, true, math_planes(), conv_pl2_pick_rbw(a.M, d->Cin)), "conv_dgrad_pl2: no kernel for this configuration");
+    return check_launch("conv_dgrad_pl2");
+}
+
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
     WgradPlan p = plan_wgrad(d, conv_math() >= 1);

@@ -1,0 +1,512 @@
+// bf16x6 implicit-GEMM convolution over pre-split activations ("planes"), second generation: one
+// (16*rbw) x 128 tile per compute unit.
+//
+// What the measurements behind this layout say (profiles/r02_notes.md):
+//   * removing the in-kernel split (conv_mfma_pl.hip vs conv_mfma_x6.hip) changes nothing by itself: the
+//     128x64-tile kernels are bound by what the CU's vector-memory path (TA / L1) can feed -- 192*(BM+BN)
+//     operand bytes per 32-deep K step against 0.094*BM*BN matrix cycles -- and by tile quantisation
+//     (a 33x33x16 map is 137 row tiles of 128: 548 workgroups leave a third of the chip idle in the last round);
+//   * LDS-DMA of 64-byte row segments (32 bf16 channels) runs at HALF the rate of 128-byte segments
+//     (12-17 vs 18-33 TB/s chip-wide from L2): a stage must hold 64 channels so every row is a whole line.
+// Hence:
+//   * tile = 16*rbw rows (rbw chosen per geometry so that tiles ~ k * 256 CUs: 144 rows for 33x33x16) x 128
+//     columns, 8 waves, ONE workgroup per CU; L1 traffic per MAC is 2.3x lower than with 128x64 tiles;
+//   * wave w owns columns 16w..16w+15 and ALL rows: its weight fragments come straight from global memory
+//     (fragment-ordered packing, 16 B per lane, 3 loads per 32-deep step) with no redundancy between waves and no
+//     LDS; the activation tile is shared through LDS and read by every wave (125 B/clk, half the LDS rate);
+//   * activation stage = 64 channels = three planes of [row][128 B], two stages (<= 120 KB), filled by LDS-DMA
+//     in 8-row x 128-B pieces; the 16-byte group g of row r sits in slot g ^ ((r >> 1) & 7), which makes the
+//     16x16x32 fragment reads (ds_read_b128) conflict-free on unpadded rows (swizzle applied to the DMA SOURCE);
+//   * v_mfma_f32_16x16x32_bf16: 16-row granularity for the tile height, and the chip holds a higher clock on it;
+//   * one barrier per 32-deep step; everything a step needs was issued a full step earlier.
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace iswm {
+
+static __device__ __attribute__((aligned(128))) unsigned short g_zero_row_pl2[64];   // 128 B of zeros
+
+typedef __attribute__((address_space(3))) void* lds_vptr2;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16b(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+
+__device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int PL2_RBWMAX = 10;     // tile height up to 160 rows
+
+// a.x = plane 0 of the gathered operand (bf16), a.ldx = its pixel pitch in bf16 elements, a.xps = plane stride (bytes)
+// a.w = weights packed by k_pack_weights_pl2;  a.MT, a.NT tile counts;  a.psplit != 0: row-major rows for strided dgrad.
+// Tile = (16 * RBW * WM) rows x (128 / WM) columns; wave (wm, wn) owns rows [wm*16*RBW, +16*RBW) and columns 16*wn..+15.
+// PERSISTENT: the grid is min(tiles, CUs) workgroups; a workgroup walks tiles  it * gridDim + xcd_remap(blockIdx)  and its
+// stage pipeline runs across tile boundaries, so a tile's epilogue overlaps the DMA of the next tile's first stage.
+template <int RBW, int WM, int NP, bool DGRAD>
+__global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
+    const int GC = DGRAD ? a.Cout : a.Cin;     // channels of the gathered operand (per tap)
+    const int NC = DGRAD ? a.Cin : a.Cout;     // output columns
+    constexpr int WN = 8 / WM, BN = 16 * WN, BM = 16 * RBW * WM, RG = BM / 8;
+    constexpr int PLANE = BM * 128;                   // bytes of one plane of one stage
+    constexpr int STAGE = NP * PLANE;
+    constexpr int NRG = (RG + 7) / 8;                 // 8-row DMA groups per wave
+    constexpr int XTRA = (DGRAD ? BM * 4 : 0) + (WM > 1 ? 4 * 128 * 4 : 0);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + XTRA];
+    int* rowpix = reinterpret_cast<int*>(smem + 2 * STAGE);
+    float* red = reinterpret_cast<float*>(smem + 2 * STAGE + (DGRAD ? BM * 4 : 0));
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vptr2)smem;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const bool par = DGRAD && a.stride == 2 && a.psplit == 0;
+    const int RH = DGRAD ? a.H : a.Ho, RW = DGRAD ? a.W : a.Wo;
+    const int GH = DGRAD ? a.Ho : a.H, GW = DGRAD ? a.Wo : a.W;
+    const int taps = a.KH * a.KW;
+    const int nCC = GC >> 6;                   // 64-channel stages per tap
+    const int K32 = a.Ktot >> 5;
+    const int ntiles = a.MT * a.NT;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+    // DMA role of this lane: row (lane >> 3) of an 8-row group, source 16-byte group gs of the 128-byte row
+    const int gs = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    const unsigned char* zrow = reinterpret_cast<const unsigned char*>(g_zero_row_pl2) + gs * 16;
+
+    // ---- issue side: the tile / tap / channel stage the DMA pointers stand on
+    int i_tile = xcd_remap(blockIdx.x, gridDim.x);      // < ntiles (grid <= ntiles)
+    int i_m0 = 0, i_n0 = 0;
+    int ihb[NRG], iwb[NRG], pb[NRG];
+    const uint4* wpk = nullptr;
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        int mt = tile / a.NT;
+        const int nt = tile - mt * a.NT;
+        if (par) {      // deal the four parity quarters of the M tiles across the XCD runs (see k_conv_x6)
+            const int qn = a.MT >> 2, rem = a.MT & 3, k = mt & 3, idx = mt >> 2;
+            mt = k * qn + (k < rem ? k : rem) + idx;
+        }
+        i_m0 = mt * BM;
+        i_n0 = nt * BN;
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) {
+            const int m = i_m0 + 8 * (wave + 8 * i) + (lane >> 3);
+            if (wave + 8 * i < RG && m < a.M) {
+                int n, rh, rw;
+                x6_row_pixel(m, a.N, RH, RW, par, n, rh, rw);
+                ihb[i] = DGRAD ? rh + a.pad : rh * a.stride - a.pad;
+                iwb[i] = DGRAD ? rw + a.pad : rw * a.stride - a.pad;
+                pb[i] = n * GH * GW;
+            } else {
+                ihb[i] = -(1 << 28);
+                iwb[i] = 0;
+                pb[i] = 0;
+            }
+        }
+        // this wave's packed weight fragments: column block (n0 >> 4) + wn; 64*NP uint4 per (column block, k32)
+        wpk = reinterpret_cast<const uint4*>(a.w) + (size_t)((i_n0 >> 4) + wn) * K32 * (64 * NP) + lane;
+    };
+    const unsigned char* aptr[NRG];
+    int astep[NRG];
+    long long pst[NRG];
+    auto setup_tap = [&](int tap) __attribute__((always_inline)) -> bool {
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int dh = kh * a.dil, dw = kw * a.dil;
+        int any = 0;
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) {
+            int gh, gw;
+            bool ok;
+            if (DGRAD) {
+                int th = ihb[i] - dh, tw = iwb[i] - dw;
+                gh = th;
+                gw = tw;
+                ok = th >= 0 && tw >= 0;
+                if (a.stride != 1) {
+                    gh = th / a.stride;
+                    gw = tw / a.stride;
+                    ok = ok && (gh * a.stride == th) && (gw * a.stride == tw);
+                }
+                ok = ok && gh < GH && gw < GW;
+            } else {
+                gh = ihb[i] + dh;
+                gw = iwb[i] + dw;
+                ok = (unsigned)gh < (unsigned)GH && (unsigned)gw < (unsigned)GW;
+            }
+            aptr[i] = ok ? xb + ((size_t)(pb[i] + gh * GW + gw) * a.ldx) * 2 + gs * 16 : zrow;
+            astep[i] = ok ? 128 : 0;
+            pst[i] = ok ? a.xps : 0;
+            any |= ok;
+        }
+        return __syncthreads_or(any) != 0;
+    };
+    int tap = -1, cc = nCC - 1;
+    auto next_in_tile = [&]() __attribute__((always_inline)) -> bool {       // advance (tap, cc) to the next 64-channel stage of this tile with work
+        if (++cc < nCC) return true;
+        cc = 0;
+        do {
+            if (++tap >= taps) return false;
+        } while (!setup_tap(tap));
+        return true;
+    };
+
+    // LDS-DMA of the whole stage the pointers stand on (8-row x 128-B pieces), then advance the pointers
+    auto issueA = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) {
+            if (wave + 8 * i < RG) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    glds16b(aptr[i] + p * pst[i], lds_base + st * STAGE + p * PLANE + (wave + 8 * i) * 1024);
+            }
+            aptr[i] += astep[i];
+        }
+    };
+    struct BFrag {
+        uint4 v[2][NP];      // [32-deep half of the stage][plane]
+    };
+    auto bload = [&](BFrag& b, int k32) __attribute__((always_inline)) {
+        const uint4* p = wpk + (size_t)k32 * (64 * NP);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) b.v[h][pl] = p[(h * NP + pl) * 64];
+    };
+
+    f32x4 acc[RBW];
+#pragma unroll
+    for (int i = 0; i < RBW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment address of this lane inside a plane: row (lane & 15) of a 16-row block, k group (lane >> 4) [+4 in the
+    // second half of the stage -> slot ^ 4 -> byte ^ 64]
+    const int fbase = wm * (RBW * 2048) + (lane & 15) * 128 + (((lane >> 4) ^ ((lane & 15) >> 1)) * 16);
+    struct AFrag {
+        uint4 v[NP];
+    };
+    auto compute = [&](int st, const BFrag& b) __attribute__((always_inline)) {
+        // fragments of row block i+1 are read while block i is multiplied; the scheduling fences keep hipcc from
+        // hoisting all 2 * RBW * NP fragment reads of a stage to its top (216 VGPRs for RBW = 9)
+        auto aload = [&](AFrag& f, int idx) __attribute__((always_inline)) {          // idx = half * RBW + rb
+            const int half = idx / RBW, rb = idx - half * RBW;
+            const unsigned char* p = smem + st * STAGE + (fbase ^ (half * 64)) + rb * 2048;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) f.v[pl] = *reinterpret_cast<const uint4*>(p + pl * PLANE);
+        };
+        auto mul = [&](const AFrag& f, int idx) __attribute__((always_inline)) {
+            const int half = idx / RBW, rb = idx - half * RBW;
+            f32x4 c = acc[rb];
+            if constexpr (NP == 3) {
+                // weights are the MFMA's row operand: lane = pixel, 4 registers = 4 consecutive channels (16-byte stores)
+                c = mfma16(b.v[half][0], f.v[2], c);     // smallest terms first: bh*al, bl*ah, bm*am, bh*am, bm*ah, bh*ah
+                c = mfma16(b.v[half][2], f.v[0], c);
+                c = mfma16(b.v[half][1], f.v[1], c);
+                c = mfma16(b.v[half][0], f.v[1], c);
+                c = mfma16(b.v[half][1], f.v[0], c);
+            }
+            c = mfma16(b.v[half][0], f.v[0], c);
+            acc[rb] = c;
+        };
+        AFrag f0, f1;
+        aload(f0, 0);
+#pragma unroll
+        for (int idx = 0; idx < 2 * RBW; idx += 2) {
+            if (idx + 1 < 2 * RBW) aload(f1, idx + 1);
+            mul(f0, idx);
+            __builtin_amdgcn_sched_barrier(0);
+            if (idx + 1 < 2 * RBW) {
+                if (idx + 2 < 2 * RBW) aload(f0, idx + 2);
+                mul(f1, idx + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- epilogue of the tile (m0, n0).  D = W . X^T per 16x16 block: lane -> pixel (lane & 15) of the row block, its 4
+    // registers -> channels 16*wn + 4*(lane >> 4) + r: one 16-byte store per row block
+    const int lq = lane >> 4, lp = lane & 15;
+    auto epilogue = [&](int tile, int m0, int n0, bool zero) __attribute__((always_inline)) {     // zero: a tile no tap reaches
+        int mt = tile / a.NT;
+        if (par) {
+            const int qn = a.MT >> 2, rem = a.MT & 3, k = mt & 3, idx = mt >> 2;
+            mt = k * qn + (k < rem ? k : rem) + idx;
+        }
+        const int col = n0 + 16 * wn + 4 * lq;
+        const bool cok = col < NC;
+        if (DGRAD && a.accumulate && zero) return;           // ... adds nothing
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!DGRAD && a.bias != nullptr && cok) bv = *reinterpret_cast<const float4*>(a.bias + col);
+        if (DGRAD && par) {
+            __syncthreads();
+            if (t < BM) {
+                const int m = m0 + t;
+                int n = 0, rh = 0, rw = 0;
+                if (m < a.M) x6_row_pixel(m, a.N, RH, RW, true, n, rh, rw);
+                rowpix[DGRAD ? t : 0] = (n * RH + rh) * RW + rw;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) {
+            const int lrw = (wm * RBW + rb) * 16 + lp;
+            const int row = m0 + lrw;
+            if (cok && row < a.M) {
+                const int pix = (DGRAD && par) ? rowpix[DGRAD ? lrw : 0] : row;
+                float4* o = reinterpret_cast<float4*>(&a.y[(size_t)pix * a.ldy + col]);
+                float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+                if (DGRAD && a.accumulate) {
+                    const float4 old = *o;
+                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                } else {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                *o = v;
+            }
+        }
+        if (!DGRAD && a.stats != nullptr) {
+            const int cnt = min(BM, a.M - m0);
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                const bool ok = !zero && m0 + (wm * RBW + rb) * 16 + lp < a.M;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] += ok ? acc[rb][r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] += __shfl_xor(s[r], 1);
+                s[r] += __shfl_xor(s[r], 2);
+                s[r] += __shfl_xor(s[r], 4);
+                s[r] += __shfl_xor(s[r], 8);
+            }
+            if constexpr (WM > 1) {                  // columns are shared by WM waves: combine through LDS
+                __syncthreads();
+                if (lp == 0) *reinterpret_cast<float4*>(&red[wm * 128 + wn * 16 + 4 * lq]) = make_float4(s[0], s[1], s[2], s[3]);
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < WM; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] += red[k * 128 + wn * 16 + 4 * lq + r];
+            }
+            float qv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                const bool ok = !zero && m0 + (wm * RBW + rb) * 16 + lp < a.M;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dv = acc[rb][r] - s[r] / (float)cnt;
+                    qv[r] += ok ? dv * dv : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                qv[r] += __shfl_xor(qv[r], 1);
+                qv[r] += __shfl_xor(qv[r], 2);
+                qv[r] += __shfl_xor(qv[r], 4);
+                qv[r] += __shfl_xor(qv[r], 8);
+            }
+            if constexpr (WM > 1) {
+                __syncthreads();
+                if (lp == 0) *reinterpret_cast<float4*>(&red[wm * 128 + wn * 16 + 4 * lq]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qv[r] = 0.f;
+#pragma unroll
+                for (int k = 0; k < WM; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) qv[r] += red[k * 128 + wn * 16 + 4 * lq + r];
+            }
+            if (lp == 0 && cok && wm == 0) {
+                *reinterpret_cast<float4*>(&a.stats[(size_t)mt * a.Cout + col]) = make_float4(s[0], s[1], s[2], s[3]);
+                *reinterpret_cast<float4*>(&a.stats[(size_t)(a.MT + mt) * a.Cout + col]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+            }
+        }
+        if (!zero) {
+#pragma unroll
+            for (int i = 0; i < RBW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- the stage stream: one pipeline step per 64-channel stage, running across this workgroup's tiles
+    int c_tile = i_tile, c_m0, c_n0;          // compute side: the tile the accumulators belong to
+    load_tile(i_tile);
+    c_m0 = i_m0;
+    c_n0 = i_n0;
+    auto next_tile = [&]() __attribute__((always_inline)) -> bool {          // issue side: step to this workgroup's next tile
+        i_tile += gridDim.x;
+        if (i_tile >= ntiles) return false;
+        load_tile(i_tile);
+        tap = -1;
+        cc = nCC - 1;
+        return true;
+    };
+    // move the issue side to the first stage of the next tile that has one; tiles without any stage (no tap reaches
+    // them: odd-parity tiles of a strided 1x1 data gradient) get their zero epilogue on the way
+    auto next_tile_stage = [&]() __attribute__((always_inline)) -> bool {
+        for (;;) {
+            if (!next_tile()) return false;
+            if (next_in_tile()) return true;
+            epilogue(i_tile, i_m0, i_n0, true);
+        }
+    };
+    {
+        BFrag bc, bn;
+        bool have = next_in_tile();
+        if (!have) {
+            epilogue(i_tile, i_m0, i_n0, true);
+            have = next_tile_stage();
+            c_tile = i_tile; c_m0 = i_m0; c_n0 = i_n0;
+        }
+        if (have) {
+            bload(bc, tap * (GC >> 5) + 2 * cc);
+            issueA(0);
+        }
+        int st = 0;
+        // one step per stage: publish stage `st`, start the loads of the following stage (possibly of the next tile),
+        // multiply stage `st`, and run the epilogue when it was the last stage of its tile
+        while (have) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's DMA pieces and weight fragments landed
+            __builtin_amdgcn_s_barrier();                // ... everyone's did; the other stage buffer is free
+            asm volatile("" ::: "memory");
+            bool more = next_in_tile();
+            const bool last = !more;                      // the stage in hand is the last of its tile
+            if (last) more = next_tile_stage();
+            if (more) {
+                bload(bn, tap * (GC >> 5) + 2 * cc);
+                issueA(st ^ 1);
+            }
+            compute(st, bc);
+            if (last) {
+                epilogue(c_tile, c_m0, c_n0, false);
+                c_tile = i_tile; c_m0 = i_m0; c_n0 = i_n0;
+            }
+            st ^= 1;
+            bc = bn;
+            have = more;
+        }
+    }
+}
+
+// Tile height for a GEMM of M rows x cols columns on 256 CUs (one 128-column workgroup per CU at a time):
+// rbw 16-row blocks, chosen to minimise  rounds x (rows per tile + fixed per-tile cost in row equivalents).
+int conv_pl2_pick_rbw(int64_t M, int cols) {
+    if (const char* e = getenv("ISWM_PL2_RBW")) {
+        const int v = atoi(e);
+        if (v >= 8 && v <= PL2_RBWMAX) return v;
+    }
+    const int64_t NT = cols <= 64 ? 1 : (cols + 127) / 128;
+    int best = PL2_RBWMAX;
+    double bestc = 1e300;
+    for (int rbw = 8; rbw <= PL2_RBWMAX; ++rbw) {
+        if (cols <= 64 && rbw == 9) continue;        // 64-column tiles: 2 wave rows x 4 or 5 blocks
+        const int64_t MT = (M + rbw * 16 - 1) / (rbw * 16);
+        const int64_t rounds = (MT * NT + 255) / 256;
+        const double c = (double)rounds * (rbw * 16 + 24.0);
+        if (c < bestc - 1e-9) {
+            bestc = c;
+            best = rbw;
+        }
+    }
+    return best;
+}
+
+// rbw = 16-row blocks per tile (8..10 instantiated for 128-column tiles; 2 x 4/5 for 64-column tiles)
+bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw) {
+    static int parity = -1, ncu = 0;
+    if (parity < 0) {
+        const char* e = getenv("ISWM_X6_PARITY");
+        parity = (e && e[0] == '0') ? 0 : 1;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+        if (const char* g = getenv("ISWM_PL2_GRID")) ncu = atoi(g) > 0 ? atoi(g) : ncu;
+    }
+    a.psplit = parity ? 0 : 1;
+    a.nsplit = rbw;
+    const int nc = dgrad ? a.Cin : a.Cout;
+    const bool narrow = nc <= 64;
+    a.MT = (a.M + rbw * 16 - 1) / (rbw * 16);
+    a.NT = narrow ? 1 : (nc + 127) / 128;
+    const int tiles = a.MT * a.NT;
+    dim3 grid(tiles < ncu ? tiles : ncu), blk(512);
+    if (planes != 3) return false;
+#define PL2_LAUNCH(R, W)                                                                       \
+    do {                                                                                       \
+        if (dgrad) hipLaunchKernelGGL((k_conv_pl2<R, W, 3, true>), grid, blk, 0, s, a);         \
+        else hipLaunchKernelGGL((k_conv_pl2<R, W, 3, false>), grid, blk, 0, s, a);              \
+    } while (0)
+    if (narrow) {
+        if (rbw == 8) PL2_LAUNCH(4, 2);
+        else if (rbw == 10) PL2_LAUNCH(5, 2);
+        else return false;
+    } else {
+        if (rbw == 8) PL2_LAUNCH(8, 1);
+        else if (rbw == 9) PL2_LAUNCH(9, 1);
+        else if (rbw == 10) PL2_LAUNCH(10, 1);
+        else return false;
+    }
+#undef PL2_LAUNCH
+    return true;
+}
+
+// Weight packing for k_conv_pl2: packed[((cb * K32 + k32) * NP + plane) * 64 + lane] (uint4) holds, for column
+// cb*16 + (lane & 15), the 8 bf16 of that plane at k = k32*32 + 8*(lane >> 4) .. +7  (the 16x16x32 B fragment).
+//   fwd  : column = cout, k = (tap, cin);   dgrad: column = cin, k = (tap, cout) (implicit transpose).
+// Columns >= NC are zero; cb runs to ceil(NC/128)*8.
+template <bool DGRAD, int NP>
+__global__ __launch_bounds__(256) void k_pack_weights_pl2(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
+                                                          int T, int Cin, int K32, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, f = idx >> 6;
+    const int k32 = f % K32, cb = f / K32;
+    const int col = cb * 16 + (lane & 15), k0 = k32 * 32 + 8 * (lane >> 4);
+    const int NC = DGRAD ? Cin : Cout, GC = DGRAD ? Cout : Cin;
+    float v[8];
+    const int tap = k0 / GC, g0 = k0 - tap * GC;      // 8 consecutive k never straddle a tap (GC % 64 == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x = 0.f;
+        if (col < NC) x = DGRAD ? w[((size_t)(g0 + i) * T + tap) * Cin + col] : w[((size_t)col * T + tap) * Cin + g0 + i];
+        v[i] = x;
+    }
+    uint4* o = packed + (size_t)f * (64 * NP) + lane;
+    if constexpr (NP == 1) {
+        const uint2 r0 = round_bf16x4(make_float4(v[0], v[1], v[2], v[3])), r1 = round_bf16x4(make_float4(v[4], v[5], v[6], v[7]));
+        o[0] = make_uint4(r0.x, r0.y, r1.x, r1.y);
+    } else {
+        uint2 h0, m0, l0, h1, m1, l1;
+        split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+        split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+size_t packed_weight_bytes_pl2(int Cout, int T, int Cin, bool dgrad, int planes) {
+    const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
+    const size_t cbs = (size_t)((NC + 127) / 128) * 8, K32 = (size_t)T * GC / 32;
+    return cbs * K32 * 64 * planes * sizeof(uint4);
+}
+
+void launch_pack_weights_pl2(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s) {
+    const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
+    const int cbs = ((NC + 127) / 128) * 8, K32 = T * GC / 32;
+    const int total = cbs * K32 * 64;
+    dim3 grid((total + 255) / 256), blk(256);
+    uint4* o = (uint4*)packed;
+    if (planes == 1) {
+        if (dgrad) hipLaunchKernelGGL((k_pack_weights_pl2<true, 1>), grid, blk, 0, s, w, o, Cout, T, Cin, K32, total);
+        else hipLaunchKernelGGL((k_pack_weights_pl2<false, 1>), grid, blk, 0, s, w, o, Cout, T, Cin, K32, total);
+    } else {
+        if (dgrad) hipLaunchKernelGGL((k_pack_weights_pl2<true, 3>), grid, blk, 0, s, w, o, Cout, T, Cin, K32, total);
+        else hipLaunchKernelGGL((k_pack_weights_pl2<false, 3>), grid, blk, 0, s, w, o, Cout, T, Cin, K32, total);
+    }
+}
+
+}  // namespace iswm
