@@ -61,7 +61,7 @@ typedef struct {
 int iswm_set_conv_math(int mode);
 int iswm_get_conv_math(void);
 /* name of the device kernel a call with this geometry launches (kind 0 fwd, 1 dgrad, 2 wgrad, 3 fwd_packed,
- * 4 dgrad_packed) --
+ * 4 dgrad_packed, 5 fwd_pl2, 6 dgrad_pl2) --
  * lets a profiler label its timings with the symbol rocprofv3 reports */
 int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen);
 /* M tiling the forward kernel will use for this geometry: rows per tile (128 or 64) and number of
@@ -121,6 +121,26 @@ int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy, const voi
  * d->ldy data gradient) counts bf16 elements and must be a multiple of 8; same call sites as iswm_conv2d_fwd. */
 int iswm_split_planes(const float* x, int64_t M, int C, int ldx, void* planes, int ldp, int64_t plane_stride,
                       iswm_stream_t stream);
+int iswm_join_planes(const void* planes, int ldp, int64_t plane_stride, int64_t M, int C, float* x, int ldx,
+                     iswm_stream_t stream);
+/* Planes-aware forms of the memory-bound passes that produce or consume convolution operands.  A tensor argument typed
+ * `void*` with a `*_ps` companion is an fp32 tensor when *_ps == 0 (pitch in floats), three bf16 planes when *_ps > 0
+ * (pitch and plane stride in bf16 elements) and one rounded bf16 plane when *_ps == -1.  The fp32-only entry points
+ * further down are these with every *_ps == 0. */
+int iswm_bn_apply_pl(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift, const float* mean,
+                     const void* residual, int ldr, int64_t res_ps, int relu, void* out, int ldo, int64_t out_ps,
+                     iswm_stream_t stream);
+int iswm_bn_backward_pl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps, const float* y, int ldy,
+                        int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                        const float* mask_scale, const float* mask_shift, int relu, int training, float* dgamma,
+                        float* dbeta, void* dy, int lddy, int64_t dy_ps, float* dres, int lddres, void* workspace,
+                        size_t workspace_bytes, iswm_stream_t stream);
+int iswm_maxpool3x3s2_fwd_pl(const float* x, int N, int H, int W, int C, void* y, int64_t y_ps, uint8_t* idx, int Ho,
+                             int Wo, iswm_stream_t stream);
+int iswm_gap_fwd_pl(const void* x, int64_t x_ps, int N, int HW, int C, int ldx, float* y, iswm_stream_t stream);
+int iswm_bcast_fwd_pl(const float* v, int N, int HW, int C, void* y, int ldy, int64_t y_ps, iswm_stream_t stream);
+int iswm_bilinear_fwd_pl(const float* x, int N, int Hi, int Wi, int C, int ldx, void* y, int64_t y_ps, int Ho, int Wo,
+                         int ldy, iswm_stream_t stream);
 int iswm_conv2d_fwd_planes(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
                            const float* bias, float* y, float* stat_partials, iswm_stream_t stream);
 int iswm_conv2d_dgrad_planes(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
@@ -133,6 +153,13 @@ int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int64_t plane_s
                         const float* bias, float* y, float* stat_partials, iswm_stream_t stream);
 int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
                           float* dx, int accumulate, iswm_stream_t stream);
+/* weight gradient with BOTH operands pre-split (x: planes of the conv input, pitch d->ldx; dy: planes of the gradient of
+ * the conv output, pitch d->ldy; pitches and plane strides in bf16 elements).  Needs Cin % 8 == 0 and Cout % 8 == 0
+ * (iswm_conv2d_wgrad_planes_ok); same result layout, workspace protocol and call sites as iswm_conv2d_wgrad. */
+int iswm_conv2d_wgrad_planes_ok(const iswm_conv_desc* d);
+size_t iswm_conv2d_wgrad_planes_workspace(const iswm_conv_desc* d);
+int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp, int64_t x_ps, const void* dyp, int64_t dy_ps, float* dw,
+                             float* workspace, size_t workspace_bytes, iswm_stream_t stream);
 /* ---- depthwise convolution (groups == channels): first half of AtrousSeparableConvolution,
  * network/_deeplab.py:95-119.  The descriptor has Cin == Cout == channel count of the (possibly zero-padded)
  * activation; w is the torch parameter [Cw][1][KH][KW] as stored, Cw <= Cin (extra channels see zero weights).

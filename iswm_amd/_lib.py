@@ -42,6 +42,14 @@ _SIGS = {
     "iswm_conv2d_fwd_packed": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P]),
     "iswm_conv2d_dgrad_packed": (c_int, [POINTER(ConvDesc), P, P, P, c_int, P]),
     "iswm_split_planes": (c_int, [P, c_int64, c_int, c_int, P, c_int, c_int64, P]),
+    "iswm_join_planes": (c_int, [P, c_int, c_int64, c_int64, c_int, P, c_int, P]),
+    "iswm_bn_apply_pl": (c_int, [P, c_int64, c_int, c_int, P, P, P, P, c_int, c_int64, c_int, P, c_int, c_int64, P]),
+    "iswm_bn_backward_pl": (c_int, [P, c_int, P, c_int, c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, c_int, c_int, P, P, P,
+                                    c_int, c_int64, P, c_int, P, c_size_t, P]),
+    "iswm_maxpool3x3s2_fwd_pl": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int64, P, c_int, c_int, P]),
+    "iswm_gap_fwd_pl": (c_int, [P, c_int64, c_int, c_int, c_int, c_int, P, P]),
+    "iswm_bcast_fwd_pl": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int64, P]),
+    "iswm_bilinear_fwd_pl": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, c_int, c_int, P]),
     "iswm_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, P, P, P]),
     "iswm_conv2d_dgrad_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P]),
     "iswm_conv2d_pl2_weight_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
@@ -49,6 +57,9 @@ _SIGS = {
     "iswm_conv2d_pl2_tile_rows": (c_int, [POINTER(ConvDesc), c_int]),
     "iswm_conv2d_fwd_pl2": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, P, P, P]),
     "iswm_conv2d_dgrad_pl2": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P]),
+    "iswm_conv2d_wgrad_planes_ok": (c_int, [POINTER(ConvDesc)]),
+    "iswm_conv2d_wgrad_planes_workspace": (c_size_t, [POINTER(ConvDesc)]),
+    "iswm_conv2d_wgrad_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, c_int64, P, P, c_size_t, P]),
     "iswm_conv2d_wgrad_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "iswm_dwconv2d_fwd": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "iswm_dwconv2d_dgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, c_int, P]),

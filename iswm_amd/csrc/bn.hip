@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
                                                   const float* __restrict__ scale,
                                                   const float* __restrict__ shift,
                                                   const float* __restrict__ mean,
-                                                  const float* __restrict__ res, int ldr,
-                                                  float* __restrict__ out, int ldo, int CQ, int RL) {
+                                                  const void* __restrict__ res, int ldr, int64_t rps,
+                                                  void* __restrict__ out, int ldo, int64_t ops, int CQ, int RL) {
     RowThread rt = row_thread(C4, CQ, RL);
     if (!rt.active) return;
     const int c = rt.c4 * 4;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
         o.x = (v.x - mu.x) * sc.x + sh.x; o.y = (v.y - mu.y) * sc.y + sh.y;
         o.z = (v.z - mu.z) * sc.z + sh.z; o.w = (v.w - mu.w) * sc.w + sh.w;
         if (RES) {
-            float4 q = ld4(res + r * ldr + c);
+            float4 q = ld4x(res, r * ldr + c, rps);
             o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
         }
         if (RELU) {
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
         if (RELU == 2) {
             o.x = fminf(o.x, 6.f); o.y = fminf(o.y, 6.f); o.z = fminf(o.z, 6.f); o.w = fminf(o.w, 6.f);
         }
-        st4(out + r * ldo + c, o);
+        st4x(out, r * ldo + c, ops, o);
     }
 }
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
 // case) -- the saved output is then never read: 8 instead of 12 bytes per element in this pass
 template <int RELU, bool DBL>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dout, int ldd,
-                                                       const float* __restrict__ out, int ldo,
+                                                       const void* __restrict__ out, int ldo, int64_t ops,
                                                        const float* __restrict__ y, int ldy, int64_t M,
                                                        int C4, int C, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
                     float4 g = ld4(dout + rr * ldd + c);
                     float4 v = ld4(y + rr * ldy + c);
                     if (RELU == 1) {
-                        float4 o = ld4(out + rr * ldo + c);
+                        float4 o = ld4x_hi(out, rr * ldo + c, ops);
                         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
                         g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
                     } else if (RELU == 3) {         // ReLU6: the gradient passes where 0 < out < 6
-                        float4 o = ld4(out + rr * ldo + c);
+                        float4 o = ld4x_hi(out, rr * ldo + c, ops);
                         g.x = (o.x > 0.f && o.x < 6.f) ? g.x : 0.f; g.y = (o.y > 0.f && o.y < 6.f) ? g.y : 0.f;
                         g.z = (o.z > 0.f && o.z < 6.f) ? g.z : 0.f; g.w = (o.w > 0.f && o.w < 6.f) ? g.w : 0.f;
                     } else if (RELU == 2) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const T* __restrict__ p
 // ---- backward stage 2 ---------------------------------------------------------------------------
 template <int RELU, bool TRAIN, bool DRES>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dout, int ldd,
-                                                      const float* __restrict__ out, int ldo,
+                                                      const void* __restrict__ out, int ldo, int64_t ops,
                                                       const float* __restrict__ y, int ldy, int64_t M,
                                                       int C4, int C, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ mscale,
                                                       const float* __restrict__ mshift,
                                                       const double* __restrict__ sums, double inv_count,
-                                                      float* __restrict__ dy, int lddy,
+                                                      void* __restrict__ dy, int lddy, int64_t dyps,
                                                       float* __restrict__ dres, int lddres, int CQ, int RL) {
     RowThread rt = row_thread(C4, CQ, RL);
     if (!rt.active) return;
@@ -330,11 +330,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (TRAIN || RELU == 2) v = ld4(y + r * ldy + c);
         if (RELU == 1) {
-            float4 o = ld4(out + r * ldo + c);
+            float4 o = ld4x_hi(out, r * ldo + c, ops);
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
         } else if (RELU == 3) {
-            float4 o = ld4(out + r * ldo + c);
+            float4 o = ld4x_hi(out, r * ldo + c, ops);
             g.x = (o.x > 0.f && o.x < 6.f) ? g.x : 0.f; g.y = (o.y > 0.f && o.y < 6.f) ? g.y : 0.f;
             g.z = (o.z > 0.f && o.z < 6.f) ? g.z : 0.f; g.w = (o.w > 0.f && o.w < 6.f) ? g.w : 0.f;
         } else if (RELU == 2) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = (float)(gi[k] * gd[k]);
         }
-        st4(dy + r * lddy + c, make_float4(d[0], d[1], d[2], d[3]));
+        st4x(dy, r * lddy + c, dyps, make_float4(d[0], d[1], d[2], d[3]));
     }
 }
 
@@ -423,18 +423,33 @@ extern "C" int iswm_bn_eval_coeffs(int C, const float* gamma, const float* beta,
     return check_launch("bn_eval_coeffs");
 }
 
+static int chk_ps(const char* what, const void* p, int64_t M, int ld, int64_t ps) {
+    ISWM_REQUIRE(ps == 0 || ps == -1 || (ps >= M * ld && ps % 4 == 0), "%s: bad plane stride %lld", what, (long long)ps);
+    ISWM_REQUIRE(ps == 0 ? aligned16(p) : ((reinterpret_cast<uintptr_t>(p) & 7) == 0), "%s: misaligned tensor", what);
+    return 0;
+}
+
 extern "C" int iswm_bn_apply(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift,
                              const float* mean, const float* residual, int ldr, int relu, float* out, int ldo,
                              iswm_stream_t stream) {
+    return iswm_bn_apply_pl(y, M, C, ldy, scale, shift, mean, residual, ldr, 0, relu, out, ldo, 0, stream);
+}
+
+extern "C" int iswm_bn_apply_pl(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift,
+                                const float* mean, const void* residual, int ldr, int64_t res_ps, int relu, void* out,
+                                int ldo, int64_t out_ps, iswm_stream_t stream) {
     if (int e = chk_rows("bn_apply", M, C, ldy)) return e;
     ISWM_REQUIRE(y && scale && shift && mean && out && ldo % 4 == 0 && ldo >= C, "bn_apply: bad argument");
     ISWM_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= C), "bn_apply: bad residual pitch");
+    if (int e = chk_ps("bn_apply(out)", out, M, ldo, out_ps)) return e;
+    if (residual) if (int e = chk_ps("bn_apply(residual)", residual, M, ldr, res_ps)) return e;
+    const int64_t rps = res_ps, ops = out_ps;
     RowPlan p = plan_rows(M, C);
     dim3 grid(p.rowblocks, p.colblocks), blk(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(R, S) \
-    hipLaunchKernelGGL((k_bn_apply<R, S>), grid, blk, 0, s, y, M, p.C4, ldy, scale, shift, mean, residual, ldr, out, \
-                       ldo, \
+    hipLaunchKernelGGL((k_bn_apply<R, S>), grid, blk, 0, s, y, M, p.C4, ldy, scale, shift, mean, residual, ldr, rps, out, \
+                       ldo, ops, \
                        p.CQ, p.RL)
     ISWM_REQUIRE(relu == 0 || relu == 1 || relu == 6, "bn_apply: relu must be 0 (none), 1 (ReLU) or 6 (ReLU6)");
     if (relu == 6 && residual) LAUNCH(2, true);
@@ -458,7 +473,19 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
                                 int relu, int training, float* dgamma, float* dbeta, float* dy, int lddy,
                                 float* dres, int lddres, void* workspace, size_t workspace_bytes,
                                 iswm_stream_t stream) {
+    return iswm_bn_backward_pl(dout, ldd, out, ldo, 0, y, ldy, M, C, mean, invstd, gamma, mask_scale, mask_shift, relu,
+                               training, dgamma, dbeta, dy, lddy, 0, dres, lddres, workspace, workspace_bytes, stream);
+}
+
+extern "C" int iswm_bn_backward_pl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps, const float* y,
+                                   int ldy, int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                                   const float* mask_scale, const float* mask_shift, int relu, int training,
+                                   float* dgamma, float* dbeta, void* dy, int lddy, int64_t dy_ps, float* dres,
+                                   int lddres, void* workspace, size_t workspace_bytes, iswm_stream_t stream) {
     if (int e = chk_rows("bn_backward", M, C, ldy)) return e;
+    if (int e = chk_ps("bn_backward(dy)", dy, M, lddy, dy_ps)) return e;
+    if (out) if (int e = chk_ps("bn_backward(out)", out, M, ldo, out_ps)) return e;
+    const int64_t ops = out_ps, dyps = dy_ps;
     // ReLU without a residual: the sign pattern is recomputed from y when the forward's scale / shift are given
     ISWM_REQUIRE(relu == 0 || relu == 1 || relu == 6, "bn_backward: relu must be 0 (none), 1 (ReLU) or 6 (ReLU6)");
     const bool relu6 = relu == 6;
@@ -478,7 +505,7 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
         RowPlan p = plan_rows(M, C, tiles);
         dim3 grid(p.rowblocks, p.colblocks), blk(256);
 #define RLAUNCH(R, D)                                                                                           \
-    hipLaunchKernelGGL((k_bn_bwd_reduce<R, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean, invstd, \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<R, D>), grid, blk, 0, s, dout, ldd, out, ldo, ops, y, ldy, M, p.C4, C, mean, invstd, \
                        mask_scale, mask_shift, p.CQ, p.RL, tiles, partials)
         const bool dbl = M <= 8192;
         if (relu6 && dbl) RLAUNCH(3, true);
@@ -503,8 +530,8 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
     dim3 grid(p.rowblocks, p.colblocks), blk(256);
     const double inv = 1.0 / (double)M;
 #define LAUNCH(R, T, D)                                                                                          \
-    hipLaunchKernelGGL((k_bn_bwd_apply<R, T, D>), grid, blk, 0, s, dout, ldd, out, ldo, y, ldy, M, p.C4, C, mean,    \
-                       invstd, gamma, mask_scale, mask_shift, sums, inv, dy, lddy, dres, lddres, p.CQ, p.RL)
+    hipLaunchKernelGGL((k_bn_bwd_apply<R, T, D>), grid, blk, 0, s, dout, ldd, out, ldo, ops, y, ldy, M, p.C4, C, mean,    \
+                       invstd, gamma, mask_scale, mask_shift, sums, inv, dy, lddy, dyps, dres, lddres, p.CQ, p.RL)
     const int key = (relu ? 4 : 0) | (training ? 2 : 0) | (dres ? 1 : 0);
     if (relu6) {
         if (training && dres) LAUNCH(3, true, true);

@@ -2,6 +2,7 @@
 // the C entry points; conv_mfma_u.hip: the tap-uniform fast path).
 #pragma once
 #include "common.h"
+#include "planes.h"
 
 namespace iswm {
 
@@ -38,39 +39,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
                                                    0, 0, 0);
-}
-
-// exact 3-way truncation split of 4 floats into packed bf16x4 planes
-__device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        unsigned xb = __float_as_uint(x[i]);
-        float r1 = x[i] - __uint_as_float(xb & 0xFFFF0000u);
-        unsigned rb = __float_as_uint(r1);
-        float r2 = r1 - __uint_as_float(rb & 0xFFFF0000u);
-        h[i] = xb;
-        m[i] = rb;
-        l[i] = __float_as_uint(r2);
-    }
-    // pack the upper halves of two words: {src0 = odd element, src1 = even element}
-    hi = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
-    mid = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
-    lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
-}
-
-
-// round-to-nearest-even conversion of 4 floats to packed bf16x4 (conv math "bf16": one plane, one MFMA per product)
-__device__ __forceinline__ uint2 round_bf16x4(const float4 v) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned u = __float_as_uint(x[i]);
-        r[i] = u + 0x7FFFu + ((u >> 16) & 1u);        // finite inputs; NaN payloads are not preserved
-    }
-    return make_uint2(__builtin_amdgcn_perm(r[1], r[0], 0x07060302u), __builtin_amdgcn_perm(r[3], r[2], 0x07060302u));
 }
 
 // GEMM row m -> pixel (n, rh, rw) of an N x RH x RW grid.  par == false: row-major.  par == true (data gradient of
@@ -114,6 +82,7 @@ void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, 
 
 // pre-split ("planes") activations, LDS-DMA staged (conv_mfma_pl.hip)
 bool launch_conv_pl(ConvArgs a, hipStream_t s, bool dgrad, int bm, int planes);
+void launch_join_planes(const unsigned short* in, int ldp, int64_t ps, int64_t M, int C, float* x, int ldx, hipStream_t s);
 void launch_split_planes(const float* x, int64_t M, int C, int ldx, unsigned short* out, int ldp, int64_t pstride_elems,
                          int planes, hipStream_t s);
 

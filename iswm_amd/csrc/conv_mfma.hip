@@ -678,6 +678,10 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restric
     }
 }
 
+void launch_reduce_slabs(const float* slabs, float* dst, int64_t n4, int nsplit, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(stream_grid(n4, 256)), dim3(256), 0, s, slabs, dst, n4, nsplit);
+}
+
 static int validate(const iswm_conv_desc* d) {
     ISWM_REQUIRE(d != nullptr, "conv: null descriptor");
     ISWM_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: empty tensor");
@@ -810,7 +814,19 @@ static PatchArgs patch_args(const iswm_conv_desc* d, bool dgrad, int PH, int PW)
 }
 
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
-    ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 4, "kernel_name: bad argument");
+    ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 7, "kernel_name: bad argument");
+    if (kind == 7) {   // iswm_conv2d_wgrad_planes
+        snprintf(buf, buflen, "k_wgrad_pl<%d>", math_planes());
+        return 0;
+    }
+    if (kind >= 5) {   // 5 / 6: iswm_conv2d_fwd_pl2 / iswm_conv2d_dgrad_pl2
+        const bool dg = kind == 6;
+        const int cols = dg ? d->Cin : d->Cout;
+        const int rbw = conv_pl2_pick_rbw(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, cols);
+        if (cols <= 64) snprintf(buf, buflen, "k_conv_pl2<%d, 2, %d, %s>", rbw / 2, math_planes(), dg ? "true" : "false");
+        else snprintf(buf, buflen, "k_conv_pl2<%d, 1, %d, %s>", rbw, math_planes(), dg ? "true" : "false");
+        return 0;
+    }
     if (kind >= 3) {   // 3 / 4: iswm_conv2d_fwd_packed / iswm_conv2d_dgrad_packed
         const bool dg = kind == 4;
         int pbm, pbn;
@@ -1056,11 +1072,20 @@ extern "C" int iswm_conv2d_dgrad_packed(const iswm_conv_desc* d, const float* dy
 extern "C" int iswm_split_planes(const float* x, int64_t M, int C, int ldx, void* planes, int ldp, int64_t plane_stride,
                                  iswm_stream_t stream) {
     ISWM_REQUIRE(x && planes && M > 0 && C > 0, "split_planes: bad argument");
-    ISWM_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldx >= C && ldp % 8 == 0 && ldp >= C, "split_planes: C %d ldx %d ldp %d", C, ldx, ldp);
-    ISWM_REQUIRE(aligned16(x) && aligned16(planes) && plane_stride % 8 == 0 && plane_stride >= M * ldp,
+    ISWM_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldx >= C && ldp % 4 == 0 && ldp >= C, "split_planes: C %d ldx %d ldp %d", C, ldx, ldp);
+    ISWM_REQUIRE(aligned16(x) && plane_stride % 4 == 0 && plane_stride >= M * ldp,
                  "split_planes: planes must be 16-byte aligned and disjoint");
     launch_split_planes(x, M, C, ldx, (unsigned short*)planes, ldp, plane_stride, math_planes(), (hipStream_t)stream);
     return check_launch("split_planes");
+}
+
+extern "C" int iswm_join_planes(const void* planes, int ldp, int64_t plane_stride, int64_t M, int C, float* x, int ldx,
+                                iswm_stream_t stream) {
+    ISWM_REQUIRE(x && planes && M > 0 && C > 0, "join_planes: bad argument");
+    ISWM_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldx >= C && ldp % 4 == 0 && ldp >= C, "join_planes: C %d ldx %d ldp %d", C, ldx, ldp);
+    ISWM_REQUIRE(plane_stride == -1 || plane_stride >= M * ldp, "join_planes: bad plane stride");
+    launch_join_planes((const unsigned short*)planes, ldp, plane_stride, M, C, x, ldx, (hipStream_t)stream);
+    return check_launch("join_planes");
 }
 
 extern "C" int iswm_conv2d_fwd_planes(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,

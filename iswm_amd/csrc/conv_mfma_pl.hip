@@ -369,6 +369,21 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
     }
 }
 
+// planes -> fp32 (x = hi + mid + lo, exact); one plane: the bf16 value
+__global__ __launch_bounds__(256) void k_join_planes(const unsigned short* __restrict__ in, int ldp, int64_t ps, int64_t M, int C4,
+                                                     float* __restrict__ x, int ldx) {
+    const int64_t total = M * C4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / C4;
+        const int c4 = (int)(i - m * C4);
+        *reinterpret_cast<float4*>(x + m * ldx + c4 * 4) = ld4x(in, m * ldp + c4 * 4, ps);
+    }
+}
+
+void launch_join_planes(const unsigned short* in, int ldp, int64_t ps, int64_t M, int C, float* x, int ldx, hipStream_t s) {
+    hipLaunchKernelGGL(k_join_planes, dim3(stream_grid(M * (C / 4), 256)), dim3(256), 0, s, in, ldp, ps, M, C / 4, x, ldx);
+}
+
 void launch_split_planes(const float* x, int64_t M, int C, int ldx, unsigned short* out, int ldp, int64_t pstride_elems,
                          int planes, hipStream_t s) {
     const int grid = stream_grid(M * (C / 4), 256);

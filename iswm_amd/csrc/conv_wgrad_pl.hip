@@ -1,0 +1,360 @@
+// Weight gradient over pre-split operands ("planes"):  dw[co][(tap, ci)] = sum_p dy[p][co] * x[p + tap][ci].
+//
+// GEMM rows = output channels, columns = the flattened (tap, input channel) axis, K = pixels.  Both operands are stored
+// pixel-major, i.e. with the GEMM K axis STRIDED and the row/column axis contiguous -- which is exactly the order an
+// LDS-DMA wants: a K step of 32 pixels x 128 channels is 32 rows of 256 B per plane, fetched in 4-row x 256-B pieces
+// (whole cache lines) with no VGPRs, no split arithmetic and no ds_write.  The k-contiguous MFMA fragments come out of
+// that [k][channel] image through gfx950's transposing LDS read (ds_read_b64_tr_b16); the 16-byte channel group g of k-row
+// k sits in slot g ^ (4 * (k & 3)) (applied to the DMA source), which puts the four k-rows of one transposing read on
+// disjoint bank quarters.
+// Tile 128 x 128, 8 waves: waves 0-3 multiply the first 16 pixels of every 32-pixel step, waves 4-7 the second 16 (each
+// wave a 64 x 64 quarter of the tile), and the two halves are added through LDS at the end -- two waves per SIMD keep the
+// matrix pipe busy while the other issues its DMA.  One workgroup per CU; the pixel axis is split across workgroups
+// (slabs summed in a fixed order by k_reduce_slabs: bit-reproducible).
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace iswm {
+
+static __device__ __attribute__((aligned(256))) unsigned short g_zero_row_wg[128];   // 256 B of zeros
+
+typedef __attribute__((address_space(3))) void* lds_vptr3;
+
+__device__ __forceinline__ void glds16w(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+
+struct WgArgs {
+    const unsigned short* dy;   // planes of dy [P][ldy]
+    const unsigned short* x;    // planes of x  [N*H*W][ldx]
+    float* out;                 // slabs [nsplit][Cout][Ktot] (or dw itself when nsplit == 1)
+    long long dyps, xps;        // plane strides in BYTES
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, ldx, ldy;
+    int P, Ktot, MT, NT, nsplit, psplit;
+    int abl;                    // timing ablations (ISWM_WG_ABL): 1 no DMA, 2 no multiply
+    int always;                 // 1: every gathered pixel is in bounds (1x1 stride-1 pad-0): no per-step culling vote
+};
+
+template <int NP>
+__global__ __launch_bounds__(512, 2) void k_wgrad_pl(const WgArgs a) {
+    constexpr int PLANE = 32 * 256;            // bytes of one plane of one operand of one stage
+    constexpr int OPER = NP * PLANE;
+    constexpr int STAGE = 2 * OPER;            // A image then B image
+    constexpr int NST = 3;                     // stage buffers: two steps in flight behind the one being multiplied
+    constexpr int SMEM = NST * STAGE < 65536 ? 65536 : NST * STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vptr3)smem;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L / a.NT, nt = L - mt * a.NT;
+    const int m0 = mt * 128, n0 = nt * 128;
+    const int split = blockIdx.y;
+    const int p_begin = split * a.psplit;
+    const int p_end = min(a.P, p_begin + a.psplit);
+    const int nK = (p_end - p_begin + 31) >> 5;
+
+    // ---- DMA role: k-row r = 4 * wave + (lane >> 4) of the 32-pixel step, LDS slot lane & 15, source channel group gsrc
+    const int kr = 4 * wave + (lane >> 4);
+    const int gsrc = (lane & 15) ^ (4 * ((lane >> 4) & 3));
+    const unsigned char* zrow = reinterpret_cast<const unsigned char*>(g_zero_row_wg) + (lane & 15) * 16;
+    // A (dy): channel m0 + 8 * gsrc
+    const int ach = m0 + 8 * gsrc;
+    const bool aok = ach < a.Cout;
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(a.dy) + (size_t)ach * 2;
+    // B (x): column n0 + 8 * gsrc of the (tap, ci) axis -> one tap and channel for the whole loop
+    const int bcol = n0 + 8 * gsrc;
+    const bool bok = bcol < a.Ktot;
+    const int tap = bok ? bcol / a.Cin : 0, bch = bok ? bcol - tap * a.Cin : 0;
+    const int tkh = tap / a.KW, tkw = tap - tkh * a.KW;
+    const int dh = tkh * a.dil - a.pad, dw = tkw * a.dil - a.pad;
+    const unsigned char* bbase = reinterpret_cast<const unsigned char*>(a.x) + (size_t)bch * 2;
+    const int HoWo = a.Ho * a.Wo;
+
+    const unsigned char* asrc = zrow;
+    const unsigned char* bsrc = zrow;
+    long long apst = 0, bpst = 0;
+    int kc = -1;
+    // pixel (n, oh, ow) of this lane's k-row in the CURRENT step, advanced by 32 pixels per step with a branch-free carry
+    // (integer divisions per step cost more VALU issue than the step's 24 MFMAs leave room for); tiny maps re-divide
+    int pn, poh, pow_;
+    {
+        const int p = p_begin + kr;
+        pn = p / HoWo;
+        const int rem = p - pn * HoWo;
+        poh = rem / a.Wo;
+        pow_ = rem - poh * a.Wo;
+    }
+    const int d_oh = 32 / a.Wo, d_ow = 32 - d_oh * a.Wo;
+    const bool fast_adv = d_oh + 1 <= a.Ho;
+    // move to the next 32-pixel step in which some gathered pixel is in bounds; leaves the DMA sources on it
+    auto next = [&]() __attribute__((always_inline)) -> bool {
+        for (;;) {
+            if (++kc >= nK) return false;
+            const int p = p_begin + kc * 32 + kr;
+            const bool pin = p < p_end;
+            asrc = (pin && aok) ? abase + (size_t)p * a.ldy * 2 : zrow;
+            apst = (pin && aok) ? a.dyps : 0;
+            if (a.always) {              // 1x1, stride 1, no padding: the gathered pixel IS p
+                const bool v = pin && bok;
+                bsrc = v ? bbase + (size_t)p * a.ldx * 2 : zrow;
+                bpst = v ? a.xps : 0;
+                return true;
+            }
+            if (kc > 0) {
+                if (fast_adv) {
+                    int ow = pow_ + d_ow;
+                    const int c1 = ow >= a.Wo ? 1 : 0;
+                    pow_ = ow - (c1 ? a.Wo : 0);
+                    int oh = poh + d_oh + c1;
+                    const int c2 = oh >= a.Ho ? 1 : 0;
+                    poh = oh - (c2 ? a.Ho : 0);
+                    pn += c2;
+                } else {
+                    pn = p / HoWo;
+                    const int rem = p - pn * HoWo;
+                    poh = rem / a.Wo;
+                    pow_ = rem - poh * a.Wo;
+                }
+            }
+            const int ih = poh * a.stride + dh, iw = pow_ * a.stride + dw;
+            const bool v = pin && bok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            bsrc = v ? bbase + (size_t)((pn * a.H + ih) * a.W + iw) * a.ldx * 2 : zrow;
+            bpst = v ? a.xps : 0;
+            if (__syncthreads_or(v ? 1 : 0)) return true;
+        }
+    };
+    auto issue = [&](int st) __attribute__((always_inline)) {
+        if (a.abl & 1) return;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) glds16w(asrc + pl * apst, lds_base + st * STAGE + pl * PLANE + wave * 1024);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) glds16w(bsrc + pl * bpst, lds_base + st * STAGE + OPER + pl * PLANE + wave * 1024);
+    };
+
+    // ---- transposing fragment reads (see conv_mfma.hip k_conv_wgrad): 16-lane group g = lane >> 4 covers rows
+    // 16 * (g & 1).. of the 32-row MFMA block for k half g >> 1; lane 4q + p of the group addresses k-row q, columns 4p..
+    const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+    const int th = tg >> 1, tc = (tg & 1) * 16 + tp * 4;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    auto tr_frag = [&](const unsigned char* plane, int col0) __attribute__((always_inline)) -> uint4 {
+        const unsigned char* p = plane + (kh * 16 + th * 8 + tq) * 256 + (((col0 + tc) * 2) ^ (tq * 64));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 256));
+        uint2 a2 = __builtin_bit_cast(uint2, lo), b2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(a2.x, a2.y, b2.x, b2.y);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int st) __attribute__((always_inline)) {
+        const unsigned char* Ax = smem + st * STAGE;
+        const unsigned char* Bx = Ax + OPER;
+        uint4 af[2][NP], bf[2][NP];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) af[mb][pl] = tr_frag(Ax + pl * PLANE, wm * 64 + mb * 32);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) bf[nb][pl] = tr_frag(Bx + pl * PLANE, wn * 64 + nb * 32);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 c = acc[mb][nb];
+                if constexpr (NP == 3) {
+                    c = mfma_bf16(af[mb][2], bf[nb][0], c);     // smallest terms first
+                    c = mfma_bf16(af[mb][0], bf[nb][2], c);
+                    c = mfma_bf16(af[mb][1], bf[nb][1], c);
+                    c = mfma_bf16(af[mb][1], bf[nb][0], c);
+                    c = mfma_bf16(af[mb][0], bf[nb][1], c);
+                }
+                c = mfma_bf16(af[mb][0], bf[nb][0], c);
+                acc[mb][nb] = c;
+            }
+    };
+
+    {
+        // three stage buffers: the DMA of a step is issued two steps ahead of its multiply (the ~1-2 us it takes to
+        // land is otherwise exposed at every barrier: a 128x128x32 step is only ~0.7 us of matrix work)
+        int nissued = 0, wr = 0, rd = 0;
+        bool src_more = true;
+        auto advance = [&]() __attribute__((always_inline)) -> bool {      // uniform: holds the culling vote
+            if (src_more && next()) return true;
+            src_more = false;
+            return false;
+        };
+        auto post = [&]() __attribute__((always_inline)) {
+            issue(wr);
+            wr = wr == NST - 1 ? 0 : wr + 1;
+            ++nissued;
+        };
+        if (advance()) post();
+        if (advance()) post();
+        while (nissued > 0) {
+            // the oldest step in flight must have landed; a younger one (2 * NP DMA instructions per wave) may stay in flight
+            if (nissued >= 2) {
+                if constexpr (NP == 3) __builtin_amdgcn_s_waitcnt(0x0F76);      // vmcnt(6)
+                else __builtin_amdgcn_s_waitcnt(0x0F72);                        // vmcnt(2)
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+            }
+            __builtin_amdgcn_s_barrier();        // everyone's pieces landed; the buffer multiplied last time is free
+            asm volatile("" ::: "memory");
+            if (advance()) post();
+            if (!(a.abl & 2)) compute(rd);
+            rd = rd == NST - 1 ? 0 : rd + 1;
+            --nissued;
+        }
+    }
+
+    // ---- combine the two k halves through LDS, then write the tile (slab of this split)
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(smem);        // [wm][wn][mb][nb][r][lane]
+    if (kh == 1) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[((((wm * 2 + wn) * 2 + mb) * 2 + nb) * 16 + r) * 64 + lane] = acc[mb][nb][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        float* out = a.out + (size_t)split * a.Cout * a.Ktot;
+        const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + wn * 64 + nb * 32 + li;
+            const bool cok = col < a.Ktot;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float v = acc[mb][nb][r] + xch[((((wm * 2 + wn) * 2 + mb) * 2 + nb) * 16 + r) * 64 + lane];
+                    if (cok && row < a.Cout) out[(size_t)row * a.Ktot + col] = v;
+                }
+        }
+    }
+}
+
+// pixels per split (multiple of 32) and split count: minimise  rounds x (steps per workgroup + fixed cost) + slab traffic
+void plan_wgrad_pl(int Cout, int Ktot, int64_t P, int* nsplit, int* psplit) {
+    const int64_t tiles = (int64_t)((Cout + 127) / 128) * ((Ktot + 127) / 128);
+    const double step_us = 0.75;                                  // one 128x128x32 step of a CU
+    const double slab_us = (double)Cout * Ktot * 8.0 / 4.0e6;     // one slab written + read at ~4 TB/s
+    int64_t maxs = (P + 255) / 256;
+    if (maxs > 256) maxs = 256;
+    if (const char* e = getenv("ISWM_WGPL_SPLIT")) {
+        const int64_t v = atoi(e);
+        if (v >= 1 && v <= maxs) {
+            const int64_t ps = ((P + v - 1) / v + 31) / 32 * 32;
+            *psplit = (int)ps;
+            *nsplit = (int)((P + ps - 1) / ps);
+            return;
+        }
+    }
+    double best = 1e300;
+    *psplit = (int)((P + 31) / 32 * 32);
+    *nsplit = 1;
+    for (int64_t ns = 1; ns <= maxs; ++ns) {
+        const int64_t ps = ((P + ns - 1) / ns + 31) / 32 * 32;
+        const int64_t nsp = (P + ps - 1) / ps;
+        const int64_t rounds = (tiles * nsp + 255) / 256;
+        const double tm = (double)rounds * ((double)(ps / 32) + 6.0) * step_us + (nsp > 1 ? (double)nsp * slab_us + 5.0 : 0.0);
+        if (tm < best) {
+            best = tm;
+            *psplit = (int)ps;
+            *nsplit = (int)nsp;
+        }
+    }
+}
+
+void launch_wgrad_pl(const WgArgs& a, int planes, hipStream_t s) {
+    dim3 grid(a.MT * a.NT, a.nsplit), blk(512);
+    if (planes == 1) hipLaunchKernelGGL(k_wgrad_pl<1>, grid, blk, 0, s, a);
+    else hipLaunchKernelGGL(k_wgrad_pl<3>, grid, blk, 0, s, a);
+}
+
+}  // namespace iswm
+
+using namespace iswm;
+
+namespace iswm {
+void launch_reduce_slabs(const float* slabs, float* dst, int64_t n4, int nsplit, hipStream_t s);
+}
+
+static int wg_validate(const iswm_conv_desc* d) {
+    ISWM_REQUIRE(d != nullptr, "wgrad_planes: null descriptor");
+    ISWM_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "wgrad_planes: empty tensor");
+    ISWM_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout,
+                 "wgrad_planes: channel counts and pitches must be multiples of 8 (Cin %d Cout %d ldx %d ldy %d)", d->Cin,
+                 d->Cout, d->ldx, d->ldy);
+    ISWM_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "wgrad_planes: bad geometry");
+    const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+    ISWM_REQUIRE(ho == d->Ho && wo == d->Wo, "wgrad_planes: output size does not match geometry");
+    ISWM_REQUIRE((int64_t)d->N * d->H * d->W * d->ldx < (1ll << 30) && (int64_t)d->N * d->Ho * d->Wo * d->ldy < (1ll << 30),
+                 "wgrad_planes: tensor too large");
+    return 0;
+}
+
+extern "C" int iswm_conv2d_wgrad_planes_ok(const iswm_conv_desc* d) {
+    return (d && d->Cin % 8 == 0 && d->Cout % 8 == 0 && iswm_get_conv_math() >= 1) ? 1 : 0;
+}
+
+extern "C" size_t iswm_conv2d_wgrad_planes_workspace(const iswm_conv_desc* d) {
+    if (!d) return 0;
+    int ns, ps;
+    plan_wgrad_pl(d->Cout, d->KH * d->KW * d->Cin, (int64_t)d->N * d->Ho * d->Wo, &ns, &ps);
+    if (ns <= 1) return 0;
+    return (size_t)ns * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+}
+
+extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp, int64_t x_ps, const void* dyp, int64_t dy_ps,
+                                        float* dw, float* workspace, size_t workspace_bytes, iswm_stream_t stream) {
+    if (int e = wg_validate(d)) return e;
+    ISWM_REQUIRE(xp && dyp && dw && aligned16(xp) && aligned16(dyp) && aligned16(dw), "wgrad_planes: bad pointer");
+    const int planes = iswm_get_conv_math() == 2 ? 1 : 3;
+    ISWM_REQUIRE(planes == 1 || (x_ps % 8 == 0 && dy_ps % 8 == 0 && x_ps > 0 && dy_ps > 0), "wgrad_planes: bad plane stride");
+    WgArgs a{};
+    a.dy = (const unsigned short*)dyp; a.x = (const unsigned short*)xp;
+    a.dyps = dy_ps * 2; a.xps = x_ps * 2;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.ldx = d->ldx; a.ldy = d->ldy;
+    a.P = d->N * d->Ho * d->Wo;
+    a.Ktot = d->KH * d->KW * d->Cin;
+    a.MT = (d->Cout + 127) / 128;
+    a.NT = (a.Ktot + 127) / 128;
+    plan_wgrad_pl(d->Cout, a.Ktot, a.P, &a.nsplit, &a.psplit);
+    static int abl = -1;
+    if (abl < 0) abl = getenv("ISWM_WG_ABL") ? atoi(getenv("ISWM_WG_ABL")) : 0;
+    a.abl = abl;
+    a.always = (d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1) ? 1 : 0;
+    const size_t need = iswm_conv2d_wgrad_planes_workspace(d);
+    ISWM_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))),
+                 "wgrad_planes: workspace too small (%zu < %zu)", workspace_bytes, need);
+    a.out = a.nsplit > 1 ? workspace : dw;
+    launch_wgrad_pl(a, planes, (hipStream_t)stream);
+    if (int e = check_launch("wgrad_planes")) return e;
+    if (a.nsplit > 1) {
+        launch_reduce_slabs(workspace, dw, (int64_t)d->Cout * a.Ktot / 4, a.nsplit, (hipStream_t)stream);
+        return check_launch("wgrad_planes_reduce");
+    }
+    return 0;
+}

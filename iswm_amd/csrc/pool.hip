@@ -8,7 +8,7 @@
 namespace iswm {
 
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x, int N, int H, int W, int C4,
-                                                     float* __restrict__ y, uint8_t* __restrict__ idx, int Ho,
+                                                     void* __restrict__ y, int64_t yps, uint8_t* __restrict__ idx, int Ho,
                                                      int Wo, int CQ, int RL) {
     RowThread rt = row_thread(C4, CQ, RL);
     if (!rt.active) return;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const float* __restrict__ x
                 if (bi[3] < 0 || v.w > best.w || v.w != v.w) { best.w = v.w; bi[3] = tap; }
             }
         }
-        st4(y + (size_t)r * C + c, best);
+        st4x(y, (int64_t)r * C + c, yps, best);
         uchar4 u = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2],
                                (unsigned char)bi[3]);
         *reinterpret_cast<uchar4*>(idx + (size_t)r * C + c) = u;
@@ -82,16 +82,16 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ d
 }
 
 // y[n, c] = mean_p x[n, p, c];  grid (1, colblocks, N)
-__global__ __launch_bounds__(256) void k_gap_fwd(const float* __restrict__ x, int HW, int C4, int ldx,
+__global__ __launch_bounds__(256) void k_gap_fwd(const void* __restrict__ x, int64_t xps, int HW, int C4, int ldx,
                                                  float* __restrict__ y, int CQ, int RL) {
     __shared__ float red[256 * 4];
     RowThread rt = row_thread(C4, CQ, RL);
     const int n = blockIdx.z;
     float4 s = make_float4(0, 0, 0, 0);
     if (rt.active) {
-        const float* p = x + (size_t)n * HW * ldx + rt.c4 * 4;
+        const int64_t p = (int64_t)n * HW * ldx + rt.c4 * 4;
         for (int r = rt.rl; r < HW; r += RL) {
-            float4 v = ld4(p + (size_t)r * ldx);
+            float4 v = ld4x(x, p + (int64_t)r * ldx, xps);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
@@ -111,19 +111,20 @@ __global__ __launch_bounds__(256) void k_gap_fwd(const float* __restrict__ x, in
 // dst[n, p, c] (=|+=) v[n, c] * mul;  grid (rowblocks, colblocks, N)
 template <bool ACC>
 __global__ __launch_bounds__(256) void k_bcast(const float* __restrict__ v, int HW, int C4, float mul,
-                                               float* __restrict__ dst, int ldd, int CQ, int RL) {
+                                               void* __restrict__ dst, int ldd, int64_t dps, int CQ, int RL) {
     RowThread rt = row_thread(C4, CQ, RL);
     if (!rt.active) return;
     const int n = blockIdx.z, c = rt.c4 * 4;
     float4 s = ld4(v + (size_t)n * C4 * 4 + c);
     s = make_float4(s.x * mul, s.y * mul, s.z * mul, s.w * mul);
-    float* p = dst + (size_t)n * HW * ldd + c;
+    const int64_t p = (int64_t)n * HW * ldd + c;
     for (int64_t r = rt.row0; r < HW; r += rt.rstep) {
         if (ACC) {
-            float4 o = ld4(p + r * ldd);
-            st4(p + r * ldd, make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w));
+            float* q = reinterpret_cast<float*>(dst) + p + r * ldd;      // accumulation targets are fp32 gradients
+            float4 o = ld4(q);
+            st4(q, make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w));
         } else {
-            st4(p + r * ldd, s);
+            st4x(dst, p + r * ldd, dps, s);
         }
     }
 }
@@ -171,11 +172,18 @@ using namespace iswm;
 
 extern "C" int iswm_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, uint8_t* idx, int Ho,
                                      int Wo, iswm_stream_t stream) {
+    return iswm_maxpool3x3s2_fwd_pl(x, N, H, W, C, y, 0, idx, Ho, Wo, stream);
+}
+
+extern "C" int iswm_maxpool3x3s2_fwd_pl(const float* x, int N, int H, int W, int C, void* y, int64_t y_ps, uint8_t* idx,
+                                        int Ho, int Wo, iswm_stream_t stream) {
     ISWM_REQUIRE(x && y && idx && C % 4 == 0 && N > 0, "maxpool_fwd: bad argument");
+    ISWM_REQUIRE(y_ps == 0 || y_ps == -1 || y_ps >= (int64_t)N * Ho * Wo * C, "maxpool_fwd: bad plane stride");
+    const int64_t yps = y_ps;
     ISWM_REQUIRE(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "maxpool_fwd: bad output size");
     RowPlan p = plan_rows((int64_t)N * Ho * Wo, C);
     hipLaunchKernelGGL(k_maxpool_fwd, dim3(p.rowblocks, p.colblocks), dim3(256), 0, (hipStream_t)stream, x, N, H,
-                       W, p.C4, y, idx, Ho, Wo, p.CQ, p.RL);
+                       W, p.C4, y, yps, idx, Ho, Wo, p.CQ, p.RL);
     return check_launch("maxpool_fwd");
 }
 
@@ -189,9 +197,13 @@ extern "C" int iswm_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, int N,
 }
 
 extern "C" int iswm_gap_fwd(const float* x, int N, int HW, int C, int ldx, float* y, iswm_stream_t stream) {
+    return iswm_gap_fwd_pl(x, 0, N, HW, C, ldx, y, stream);
+}
+
+extern "C" int iswm_gap_fwd_pl(const void* x, int64_t x_ps, int N, int HW, int C, int ldx, float* y, iswm_stream_t stream) {
     ISWM_REQUIRE(x && y && C % 4 == 0 && ldx % 4 == 0 && ldx >= C && N > 0 && HW > 0, "gap_fwd: bad argument");
     RowPlan p = plan_reduce(C);
-    hipLaunchKernelGGL(k_gap_fwd, dim3(1, p.colblocks, N), dim3(256), 0, (hipStream_t)stream, x, HW, p.C4, ldx, y,
+    hipLaunchKernelGGL(k_gap_fwd, dim3(1, p.colblocks, N), dim3(256), 0, (hipStream_t)stream, x, x_ps, HW, p.C4, ldx, y,
                        p.CQ, p.RL);
     return check_launch("gap_fwd");
 }
@@ -204,18 +216,22 @@ extern "C" int iswm_gap_bwd(const float* dy, int N, int HW, int C, float* dx, in
     const float mul = 1.f / (float)HW;
     if (accumulate)
         hipLaunchKernelGGL((k_bcast<true>), grid, dim3(256), 0, (hipStream_t)stream, dy, HW, p.C4, mul, dx, lddx,
-                           p.CQ, p.RL);
+                           (int64_t)0, p.CQ, p.RL);
     else
         hipLaunchKernelGGL((k_bcast<false>), grid, dim3(256), 0, (hipStream_t)stream, dy, HW, p.C4, mul, dx, lddx,
-                           p.CQ, p.RL);
+                           (int64_t)0, p.CQ, p.RL);
     return check_launch("gap_bwd");
 }
 
 extern "C" int iswm_bcast_fwd(const float* v, int N, int HW, int C, float* y, int ldy, iswm_stream_t stream) {
+    return iswm_bcast_fwd_pl(v, N, HW, C, y, ldy, 0, stream);
+}
+
+extern "C" int iswm_bcast_fwd_pl(const float* v, int N, int HW, int C, void* y, int ldy, int64_t y_ps, iswm_stream_t stream) {
     ISWM_REQUIRE(v && y && C % 4 == 0 && ldy % 4 == 0 && ldy >= C && N > 0 && HW > 0, "bcast_fwd: bad argument");
     RowPlan p = plan_rows(HW, C);
     hipLaunchKernelGGL((k_bcast<false>), dim3(p.rowblocks, p.colblocks, N), dim3(256), 0, (hipStream_t)stream, v,
-                       HW, p.C4, 1.f, y, ldy, p.CQ, p.RL);
+                       HW, p.C4, 1.f, y, ldy, y_ps, p.CQ, p.RL);
     return check_launch("bcast_fwd");
 }
 

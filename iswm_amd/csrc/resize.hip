@@ -42,7 +42,7 @@ __device__ __forceinline__ float weight_for(const Lerp& l, int i) {
 }
 
 __global__ __launch_bounds__(256) void k_bilinear_fwd(const float* __restrict__ x, int N, int Hi, int Wi, int C4,
-                                                      int ldx, float* __restrict__ y, int Ho, int Wo, int ldy,
+                                                      int ldx, void* __restrict__ y, int64_t yps, int Ho, int Wo, int ldy,
                                                       float sh, float sw, int CQ, int RL) {
     RowThread rt = row_thread(C4, CQ, RL);
     if (!rt.active) return;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_bilinear_fwd(const float* __restrict__ 
         o.y = lh.l0 * (lw.l0 * a.y + lw.l1 * b.y) + lh.l1 * (lw.l0 * d.y + lw.l1 * e.y);
         o.z = lh.l0 * (lw.l0 * a.z + lw.l1 * b.z) + lh.l1 * (lw.l0 * d.z + lw.l1 * e.z);
         o.w = lh.l0 * (lw.l0 * a.w + lw.l1 * b.w) + lh.l1 * (lw.l0 * d.w + lw.l1 * e.w);
-        st4(y + (size_t)r * ldy + c, o);
+        st4x(y, (int64_t)r * ldy + c, yps, o);
     }
 }
 
@@ -193,12 +193,18 @@ using namespace iswm;
 
 extern "C" int iswm_bilinear_fwd(const float* x, int N, int Hi, int Wi, int C, int ldx, float* y, int Ho, int Wo,
                                  int ldy, iswm_stream_t stream) {
+    return iswm_bilinear_fwd_pl(x, N, Hi, Wi, C, ldx, y, 0, Ho, Wo, ldy, stream);
+}
+
+extern "C" int iswm_bilinear_fwd_pl(const float* x, int N, int Hi, int Wi, int C, int ldx, void* y, int64_t y_ps, int Ho,
+                                    int Wo, int ldy, iswm_stream_t stream) {
+    ISWM_REQUIRE(y_ps == 0 || y_ps == -1 || y_ps >= (int64_t)N * Ho * Wo * ldy, "bilinear_fwd: bad plane stride");
     ISWM_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 4 == 0 && ldx % 4 == 0 &&
                      ldy % 4 == 0 && ldx >= C && ldy >= C,
                  "bilinear_fwd: bad argument");
     RowPlan p = plan_rows((int64_t)N * Ho * Wo, C);
     hipLaunchKernelGGL(k_bilinear_fwd, dim3(p.rowblocks, p.colblocks), dim3(256), 0, (hipStream_t)stream, x, N, Hi,
-                       Wi, p.C4, ldx, y, Ho, Wo, ldy, (float)Hi / (float)Ho, (float)Wi / (float)Wo, p.CQ, p.RL);
+                       Wi, p.C4, ldx, y, y_ps, Ho, Wo, ldy, (float)Hi / (float)Ho, (float)Wi / (float)Wo, p.CQ, p.RL);
     return check_launch("bilinear_fwd");
 }
 

@@ -5,6 +5,7 @@
 // reads CQ consecutive float4 = one coalesced run.
 #pragma once
 #include "common.h"
+#include "planes.h"
 
 namespace iswm {
 

@@ -59,7 +59,7 @@ class ASPPPooling(_hip.HipSequential):
     def fwd(self, x, save, out=None):
         n, h, w, c = x.shape
         pooled = ops.gap_fwd(x)                                            # [N,1,1,C]
-        v, ctx = _hip.cba_fwd(self[1], self[2], True, pooled, save)       # BN over N x 1 x 1 (needs N >= 2)
+        v, ctx = _hip.cba_fwd(self[1], self[2], True, pooled, save, out_fmt="f32")   # BN over N x 1 x 1 (needs N >= 2)
         if out is None:
             out = ops.new_act(n, h, w, v.shape[3], x.device)
         ops.bcast_fwd(v, out)                                              # bilinear from 1x1 == broadcast
@@ -102,7 +102,11 @@ class ASPP(_hip.HipModule):
     def fwd(self, x, save, out=None):
         n, h, w, _ = x.shape
         oc = self.project[0].in_channels // len(self.convs)
-        cat = ops.new_act(n, h, w, oc * len(self.convs), x.device)
+        # the five branches write their slices of one buffer, pre-split for the projection conv
+        if ops.planes_on() and (oc * len(self.convs)) % 64 == 0:
+            cat = ops.new_planes(n, h, w, oc * len(self.convs), x.device)
+        else:
+            cat = ops.new_act(n, h, w, oc * len(self.convs), x.device)
         for i, conv in enumerate(self.convs):
             conv.fwd(x, save, out=cat[..., i * oc:(i + 1) * oc])
         self._saved = (tuple(x.shape), oc) if save else None
@@ -153,7 +157,10 @@ class DeepLabHeadV3Plus(_hip.HipModule):
         c_aspp = self.aspp.project[0].out_channels
         c_cat = c_low + c_aspp
         c_buf = self.classifier[0].cin_p            # 304 -> 320: zero channels keep the K axis a multiple of 32
-        cat = ops.new_act(n, hl, wl, c_buf, low.device)
+        if ops.planes_on() and c_buf % 64 == 0:
+            cat = ops.new_planes(n, hl, wl, c_buf, low.device)
+        else:
+            cat = ops.new_act(n, hl, wl, c_buf, low.device)
         if c_buf > c_cat:
             cat[..., c_cat:].zero_()
         self.project.fwd(low, save, out=cat[..., :c_low])

@@ -170,6 +170,14 @@ class Conv2d(HipModule, nn.Conv2d):
         wp[:self.out_channels, :, :, :self.in_channels] = v
         return wp
 
+    def packed2(self, kind):
+        """this weight pre-packed for the planes kernels (csrc/conv_mfma_pl2.hip) by the WeightPacker, or None"""
+        e = getattr(self, "_iswm_wpk", None)
+        if e is None or not e["live"] or e["epoch"] != ops.WEIGHTS_EPOCH or e["version"] != self.weight._version or \
+                e["ptr"] != self.weight.data_ptr():
+            return None
+        return e["buf"].get(kind + 2)
+
     def packed(self, kind):
         """this weight pre-packed for the bf16x6 forward (0) / data-gradient (1) kernel by the model's WeightPacker,
         or None (the kernel wrappers then pack it themselves).  Valid only inside the forward/backward window it was
@@ -214,7 +222,7 @@ class Conv2d(HipModule, nn.Conv2d):
     # -- standalone conv (+bias), e.g. the final 1x1 classifier ---------------------------
     def fwd(self, x, save, out=None):
         g = self.geometry(x)
-        y, _, _ = ops.conv2d_fwd(x, self.ohwi(), g, bias=self.bias_p(), out=out, wpk=self.packed(0))
+        y, _, _ = ops.conv2d_fwd(x, self.ohwi(), g, bias=self.bias_p(), out=out, wpk=self.packed(0), wpk2=self.packed2(0))
         self._saved = (x, g) if save else None
         return y
 
@@ -227,7 +235,7 @@ class Conv2d(HipModule, nn.Conv2d):
         self.write_wgrad(x, dy, g, sink)
         if not need_dx:
             return None
-        return ops.conv2d_dgrad(dy, self.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=self.packed(1))
+        return ops.conv2d_dgrad(dy, self.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=self.packed(1), wpk2=self.packed2(1))
 
     def out_channels_of(self, cin):
         return self.out_channels
@@ -321,9 +329,10 @@ class Dropout(HipModule, nn.Dropout):
 # ---------------------------------------------------------------------------------------
 # conv -> BatchNorm -> (+residual) -> ReLU, the unit every stage of the net is made of
 # ---------------------------------------------------------------------------------------
-def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
+def cba_fwd(conv, bn, relu, x, save, residual=None, out=None, out_fmt=None):
     """Returns (out, ctx).  Training-mode BN statistics come from the conv epilogue's
-    per-tile partial sums (no extra pass over y)."""
+    per-tile partial sums (no extra pass over y).  The output is written pre-split (ops.Planes) when a convolution
+    will consume it: `out` (a buffer slice) decides, else out_fmt ("planes" / "f32"), else the channel count."""
     sep = None
     if isinstance(conv, SeparableBase):         # depthwise first, then the pointwise conv carries the fused BN
         sep, conv = conv, conv.body[1]
@@ -338,10 +347,10 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
         if training:
             partials, nt, tr = ops.colstat(y)
             tiles = (nt, tr)
-        return _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, True)
+        return _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, True, out_fmt)
     g = conv.geometry(x)
     if conv.bias is None:
-        y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training, wpk=conv.packed(0))
+        y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training, wpk=conv.packed(0), wpk2=conv.packed2(0))
     else:
         # a biased conv in front of a BatchNorm (only reachable through convert_to_separable_conv on a biased
         # conv): the fused epilogue statistics do not include the bias, so take them in a separate column pass
@@ -350,10 +359,10 @@ def cba_fwd(conv, bn, relu, x, save, residual=None, out=None):
         if training:
             partials, nt, tr = ops.colstat(y)
             tiles = (nt, tr)
-    return _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, False)
+    return _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, False, out_fmt)
 
 
-def _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, dw):
+def _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residual, out, sep, dw, out_fmt=None):
     if training:
         count = y.shape[0] * y.shape[1] * y.shape[2]
         if count <= 1:
@@ -366,9 +375,14 @@ def _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residu
             bn.num_batches_tracked.add_(1)     # models built by modeling.* bump all counters in ONE op
     else:
         coef = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-    o = ops.bn_apply(y, coef, relu, residual, out)
+    if out_fmt is None:
+        want_planes = ops.planes_on() and y.shape[3] % 64 == 0
+    else:
+        want_planes = out_fmt == "planes" and ops.planes_on() and y.shape[3] % 64 == 0
+    o = ops.bn_apply(y, coef, relu, residual, out, planes=want_planes)
     if MASK_RECORDER is not None and relu:
-        MASK_RECORDER[bn] = (o > 0) & (o < 6) if relu == 6 and relu is not True else (o > 0)
+        of = ops.as_f32(o)
+        MASK_RECORDER[bn] = (of > 0) & (of < 6) if relu == 6 and relu is not True else (of > 0)
     ctx = None
     if save:
         ctx = dict(x=x, y=y, out=o, coef=coef, g=g, relu=relu, training=training, res=residual is not None, sep=sep, dw=dw)
@@ -384,8 +398,10 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
     gw, gb = bn.weight, bn.bias
     dgamma = sink.target(gw) if gw.requires_grad else torch.empty_like(gw)
     dbeta = sink.target(gb) if gb.requires_grad else torch.empty_like(gb)
-    dy, dres = ops.bn_backward(dout, o if ctx["relu"] else None, y, ctx["coef"], gw, ctx["relu"], ctx["training"],
-                               dgamma, dbeta, want_dres=ctx["res"])
+    # dy goes out pre-split when the data-gradient kernel takes planes (and the conv is not a depthwise one)
+    dyp = (not ctx.get("dw")) and ops.planes_conv_ok(conv.cin_p, conv.cout_p, 1)
+    dy, dres = ops.bn_backward(ops.as_f32(dout), o if ctx["relu"] else None, y, ctx["coef"], gw, ctx["relu"], ctx["training"],
+                               dgamma, dbeta, want_dres=ctx["res"], dy_planes=dyp)
     if gw.requires_grad:
         sink.done(gw)
     if gb.requires_grad:
@@ -397,10 +413,10 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
         sink.target(conv.bias).copy_(ops.colsum(dy)[:conv.out_channels])
         sink.done(conv.bias)
     if sep is not None:
-        dmid = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), wpk=conv.packed(1))
+        dmid = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), wpk=conv.packed(1), wpk2=conv.packed2(1))
         return sep.body[0].bwd(dmid, sink, need_dx, dx, accumulate), dres
     if need_dx:
-        dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=conv.packed(1))
+        dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=conv.packed(1), wpk2=conv.packed2(1))
     else:
         dx = None
     return dx, dres
@@ -526,13 +542,21 @@ class HipSequential(HipModule, nn.Sequential):
                 raise NotImplementedError("no HIP implementation for %s inside a Sequential" % type(m).__name__)
         return st
 
-    def fwd(self, x, save, out=None):
+    def fwd(self, x, save, out=None, out_fmt=None):
         st = self._stages()
         ctxs = []
         for k, s in enumerate(st):
             last = k == len(st) - 1
             if s[0] == "cba":
-                x, c = cba_fwd(s[1], s[2], s[3], x, save, out=out if last else None)
+                # the stage's output is pre-split when the next stage is a convolution; the last stage follows `out`
+                # / out_fmt (default fp32: the caller is not a conv unless it says so)
+                if last:
+                    fmt = out_fmt if out is None else None
+                    if out is None and out_fmt is None:
+                        fmt = "f32"
+                else:
+                    fmt = "planes" if st[k + 1][0] in ("cba", "conv") else "f32"
+                x, c = cba_fwd(s[1], s[2], s[3], x, save, out=out if last else None, out_fmt=fmt)
                 ctxs.append(c)
             elif s[0] == "conv":
                 x = s[1].fwd(x, save, out=out if last else None)

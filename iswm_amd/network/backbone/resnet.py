@@ -100,7 +100,8 @@ class MaxPool2d(_hip.HipModule, nn.MaxPool2d):
     def fwd(self, x, save):
         if (self.kernel_size, self.stride, self.padding) != (3, 2, 1):
             raise NotImplementedError("HIP max-pool is the stem's 3x3 / stride 2 / pad 1")
-        y, idx = ops.maxpool_fwd(x)
+        # layer1 follows: its 1x1 convs take the pooled map pre-split
+        y, idx = ops.maxpool_fwd(x, planes=ops.planes_on() and x.shape[3] % 64 == 0)
         self._saved = (idx, tuple(x.shape)) if save else None
         return y
 

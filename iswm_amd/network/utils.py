@@ -139,7 +139,9 @@ class IntermediateLayerGetter(nn.ModuleDict):
         stem_ctx = None
         for name, module in self.named_children():
             if name == "conv1":
-                x, stem_ctx = _hip.cba_fwd(self["conv1"], self["bn1"], True, x, save)
+                # the max-pool reads the stem's output as fp32
+                fmt = "f32" if "maxpool" in self._modules else None
+                x, stem_ctx = _hip.cba_fwd(self["conv1"], self["bn1"], True, x, save, out_fmt=fmt)
             elif name in ("bn1", "relu"):
                 pass                                   # fused into the conv1 stage above
             else:
@@ -169,4 +171,4 @@ class IntermediateLayerGetter(nn.ModuleDict):
 
     def forward(self, x):
         feats = self.fwd(ops.nchw_to_nhwc(x), False)
-        return OrderedDict((k, ops.nhwc_to_nchw(v)) for k, v in feats.items())
+        return OrderedDict((k, ops.nhwc_to_nchw(v)) for k, v in feats.items())     # (joins pre-split features)

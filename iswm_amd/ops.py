@@ -28,9 +28,11 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def geom(t):
+def geom(t, dtype=torch.float32):
     """(N, H, W, C, ld) of an NHWC activation view; raises on any other layout."""
-    if t.dim() != 4 or t.dtype != torch.float32 or not t.is_cuda:
+    if isinstance(t, Planes):
+        raise ValueError("this operation takes an fp32 NHWC tensor, not Planes (use .f32())")
+    if t.dim() != 4 or t.dtype != dtype or not t.is_cuda:
         raise ValueError("expected a 4-D fp32 CUDA NHWC tensor, got %s %s %s" % (tuple(t.shape), t.dtype, t.device))
     n, h, w, c = t.shape
     if w > 1:
@@ -50,6 +52,90 @@ def geom(t):
 
 def new_act(n, h, w, c, device):
     return torch.empty((n, h, w, c), dtype=torch.float32, device=device)
+
+
+# ---- "planes": activations stored pre-split for the bf16x6 convolution kernels (csrc/planes.h) -------------
+# ISWM_PLANES=0 keeps every activation fp32 (the round-1 data path); conv math f32 / bf16 do that too.
+_PLANES_ENV = os.environ.get("ISWM_PLANES", "1") != "0"
+_WGRAD_PLANES = os.environ.get("ISWM_WGRAD_PLANES", "1") != "0"     # tuning switch: 0 joins the planes and runs the fp32-input weight gradient
+
+
+def planes_on():
+    return _PLANES_ENV and _lib.load().iswm_get_conv_math() == 1
+
+
+class Planes(object):
+    """An NHWC fp32 activation held as its exact 3-way bf16 split: `t` is a bf16 tensor [3, N, H, W, C]
+    (plane, then a pitched NHWC view), hi + mid + lo == the fp32 value bit for bit.  Producers (BatchNorm / pooling /
+    resize passes) write it, the convolution kernels stage it into LDS by DMA; anything else asks for `.f32()`."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        assert t.dim() == 5 and t.dtype == torch.bfloat16 and t.shape[0] == 3
+        self.t = t
+
+    @property
+    def shape(self):
+        return self.t.shape[1:]
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def dim(self):
+        return 4
+
+    def __getitem__(self, idx):
+        if not (isinstance(idx, tuple) and len(idx) == 2 and idx[0] is Ellipsis and isinstance(idx[1], slice)):
+            raise IndexError("Planes supports channel slices x[..., a:b] only")
+        return Planes(self.t[..., idx[1]])
+
+    def f32(self):
+        n, h, w, c, ld, ps = pgeom(self)
+        out = new_act(n, h, w, c, self.t.device)
+        call("iswm_join_planes", _p(self.t), ld, ps, n * h * w, c, _p(out), c, _stream())
+        return out
+
+    def zero_(self):
+        self.t.zero_()
+        return self
+
+
+def is_planes(x):
+    return isinstance(x, Planes)
+
+
+def as_f32(x):
+    return x.f32() if isinstance(x, Planes) else x
+
+
+def new_planes(n, h, w, c, device, zero=False):
+    mk = torch.zeros if zero else torch.empty
+    return Planes(mk((3, n, h, w, c), dtype=torch.bfloat16, device=device))
+
+
+def pgeom(x):
+    """(N, H, W, C, ld, plane stride) of a Planes tensor, both in bf16 elements"""
+    n, h, w, c, ld = geom(x.t[0], torch.bfloat16)
+    return n, h, w, c, ld, x.t.stride(0)
+
+
+def xgeom(x):
+    """(pointer tensor, N, H, W, C, ld, ps) of an fp32 NHWC tensor (ps = 0) or a Planes tensor"""
+    if isinstance(x, Planes):
+        return (x.t,) + pgeom(x)
+    return (x,) + geom(x) + (0,)
+
+
+def split_planes(x, out=None):
+    """fp32 NHWC -> Planes (one extra pass; producers normally write planes themselves)"""
+    n, h, w, c, ld = geom(x)
+    if out is None:
+        out = new_planes(n, h, w, c, x.device)
+    _, _, _, _, ldp, ps = pgeom(out)
+    call("iswm_split_planes", _p(x), n * h * w, c, ld, _p(out.t), ldp, ps, _stream())
+    return out
 
 
 class KernelProfile:
@@ -129,7 +215,7 @@ class ConvGeom:
     """Static geometry of one conv call (wraps iswm_conv_desc)."""
 
     def __init__(self, x, cout, kh, kw, stride, pad, dil):
-        n, h, w, cin, ldx = geom(x)
+        n, h, w, cin = x.shape
         self.n, self.h, self.w, self.cin, self.cout = n, h, w, cin, cout
         self.kh, self.kw, self.stride, self.pad, self.dil = kh, kw, stride, pad, dil
         self.ho = conv_out_size(h, kh, stride, pad, dil)
@@ -207,15 +293,32 @@ def weights_changed():
     WEIGHTS_EPOCH += 1
 
 
-def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False, wpk=None):
+def conv2d_fwd(x, w_ohwi, g, bias=None, out=None, want_stats=False, wpk=None, wpk2=None):
     """y = conv(x, w) [+ bias]; returns (y, partials|None, (tiles, tile_rows)).  wpk: this weight already packed
     for the forward kernel (network._hip.WeightPacker), else it is packed here."""
-    ldx = geom(x)[4]
     _check_w(w_ohwi, g)
     if out is None:
         out = new_act(g.n, g.ho, g.wo, g.cout, x.device)
     on, oh, ow, oc, ldy = geom(out)
     assert (on, oh, ow, oc) == (g.n, g.ho, g.wo, g.cout)
+    if isinstance(x, Planes):
+        _, _, _, _, ldp, ps = pgeom(x)
+        d = g.desc(ldp, ldy)
+        nb2 = _pl2_bytes(d, 0)
+        if nb2:
+            partials, tiles = None, (0, 0)
+            if want_stats:
+                tr = _lib.load().iswm_conv2d_pl2_tile_rows(ctypes.byref(d), 0)
+                tiles = ((g.n * g.ho * g.wo + tr - 1) // tr, tr)
+                partials = torch.empty((2, tiles[0], g.cout), dtype=torch.float32, device=out.device)
+            if wpk2 is None:
+                wpk2 = torch.empty((nb2 // 4,), dtype=torch.float32, device=out.device)
+                call("iswm_conv2d_pl2_pack_weights", ctypes.byref(d), 0, _p(w_ohwi), _p(wpk2), _stream())
+            with _timed(d, 5, g):
+                call("iswm_conv2d_fwd_pl2", ctypes.byref(d), _p(x.t), ps, _p(wpk2), _p(bias), _p(out), _p(partials), _stream())
+            return out, partials, tiles
+        x = x.f32()
+    ldx = geom(x)[4]
     d = g.desc(ldx, ldy)
     partials, tiles = None, (0, 0)
     if want_stats:
@@ -248,15 +351,37 @@ def _packed_bytes(d, kind):
     return _lib.load().iswm_conv2d_packed_weight_bytes(ctypes.byref(d), kind) if _USE_PACKED else 0
 
 
-def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=None):
+def _pl2_bytes(d, kind):
+    """packed-weight bytes of the planes kernels for this geometry, 0 when they do not apply"""
+    return _lib.load().iswm_conv2d_pl2_weight_bytes(ctypes.byref(d), kind) if planes_on() else 0
+
+
+def planes_conv_ok(cin, cout, kind):
+    """will a conv with these channel counts take a Planes operand (kind 0: x forward, 1: dy data gradient)?"""
+    return planes_on() and (cout if kind else cin) % 64 == 0
+
+
+def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=None, wpk2=None):
     """dx (=|+=) conv^T(dy, w).  x_like_shape = (N,H,W,Cin) of the conv input.  wpk: weight already packed for the
-    data-gradient kernel."""
-    ldy = geom(dy)[4]
+    data-gradient kernel (wpk2: for the planes kernel)."""
     _check_w(w_ohwi, g)
     if dx is None:
         assert not accumulate
         dx = new_act(*x_like_shape, dy.device)
     ldx = geom(dx)[4]
+    if isinstance(dy, Planes):
+        _, _, _, _, ldp, ps = pgeom(dy)
+        d = g.desc(ldx, ldp)
+        nb2 = _pl2_bytes(d, 1)
+        if nb2:
+            if wpk2 is None:
+                wpk2 = torch.empty((nb2 // 4,), dtype=torch.float32, device=dx.device)
+                call("iswm_conv2d_pl2_pack_weights", ctypes.byref(d), 1, _p(w_ohwi), _p(wpk2), _stream())
+            with _timed(d, 6, g):
+                call("iswm_conv2d_dgrad_pl2", ctypes.byref(d), _p(dy.t), ps, _p(wpk2), _p(dx), int(bool(accumulate)), _stream())
+            return dx
+        dy = dy.f32()
+    ldy = geom(dy)[4]
     d = g.desc(ldx, ldy)
     nb = _packed_bytes(d, 1)
     if nb:
@@ -279,11 +404,30 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=Non
 
 
 def conv2d_wgrad(x, dy, g, dw_ohwi=None):
-    """dw[Cout,KH,KW,Cin] = sum_pixels dy (x) gathered x."""
-    ldx, ldy = geom(x)[4], geom(dy)[4]
+    """dw[Cout,KH,KW,Cin] = sum_pixels dy (x) gathered x.  With a pre-split x the planes kernel runs (dy is split
+    here when the producer did not: the few-channel classifier gradient)."""
     if dw_ohwi is None:
         dw_ohwi = torch.empty((g.cout, g.kh, g.kw, g.cin), dtype=torch.float32, device=x.device)
     _check_w(dw_ohwi, g)
+    if isinstance(x, Planes) and planes_on() and g.cin % 8 == 0 and _WGRAD_PLANES:
+        c8 = (g.cout + 7) // 8 * 8
+        if not isinstance(dy, Planes) or c8 != g.cout:
+            dyf = as_f32(dy)
+            dy = new_planes(g.n, g.ho, g.wo, c8, x.device, zero=c8 != g.cout)
+            split_planes(dyf, out=dy[..., :g.cout] if c8 != g.cout else dy)
+        _, _, _, _, ldx, psx = pgeom(x)
+        _, _, _, _, ldy, psy = pgeom(dy)
+        d = ConvDesc(g.n, g.h, g.w, g.cin, g.ho, g.wo, c8, g.kh, g.kw, g.stride, g.pad, g.dil, ldx, ldy)
+        need = _lib.load().iswm_conv2d_wgrad_planes_workspace(ctypes.byref(d))
+        ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device) if need else None
+        tgt = dw_ohwi if c8 == g.cout else torch.empty((c8, g.kh, g.kw, g.cin), dtype=torch.float32, device=x.device)
+        with _timed(d, 7, g, "+reduce"):
+            call("iswm_conv2d_wgrad_planes", ctypes.byref(d), _p(x.t), psx, _p(dy.t), psy, _p(tgt), _p(ws), need, _stream())
+        if tgt is not dw_ohwi:
+            dw_ohwi.copy_(tgt[:g.cout])
+        return dw_ohwi
+    x, dy = as_f32(x), as_f32(dy)
+    ldx, ldy = geom(x)[4], geom(dy)[4]
     d = g.desc(ldx, ldy)
     need = _lib.load().iswm_conv2d_wgrad_workspace(ctypes.byref(d))
     ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device) if need else None
@@ -295,6 +439,7 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
 # ---- depthwise conv (groups == channels) -------------------------------------------------------------
 def dwconv2d_fwd(x, w, g, bias=None, out=None):
     """x NHWC [N,H,W,C]; w the parameter [Cw,1,KH,KW] (contiguous), Cw <= C"""
+    x = as_f32(x)
     ldx = geom(x)[4]
     if out is None:
         out = new_act(g.n, g.ho, g.wo, g.cin, x.device)
@@ -314,6 +459,7 @@ def dwconv2d_dgrad(dy, w, g, x_like_shape, dx=None, accumulate=False):
 
 def dwconv2d_wgrad(x, dy, g, cw, dw=None):
     """dw [Cw,1,KH,KW]"""
+    x, dy = as_f32(x), as_f32(dy)
     if dw is None:
         dw = torch.empty((cw, 1, g.kh, g.kw), dtype=torch.float32, device=x.device)
     d = g.desc(geom(x)[4], geom(dy)[4])
@@ -326,6 +472,12 @@ def dwconv2d_wgrad(x, dy, g, cw, dw=None):
 def rows(t):
     n, h, w, c, ld = geom(t)
     return n * h * w, c, ld
+
+
+def xrows(t):
+    """(pointer tensor, rows, C, ld, ps) of an fp32 or Planes activation"""
+    p, n, h, w, c, ld, ps = xgeom(t)
+    return p, n * h * w, c, ld, ps
 
 
 def colstat(x):
@@ -359,46 +511,54 @@ def _relu_code(relu):
     return 6 if (relu == 6 and relu is not True) else int(bool(relu))
 
 
-def bn_apply(y, coef, relu, residual=None, out=None):
+def bn_apply(y, coef, relu, residual=None, out=None, planes=False):
+    """out = act((y - mean) * scale + beta (+ residual)); `out` (fp32 or Planes, possibly a channel slice) decides the
+    output format, else `planes` does"""
     m, c, ldy = rows(y)
     if out is None:
-        out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
-    mo, co, ldo = rows(out)
+        out = new_planes(*y.shape, y.device) if planes else torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    po, mo, co, ldo, pso = xrows(out)
     assert (mo, co) == (m, c)
-    ldr = 0
+    pr, ldr, psr = None, 0, 0
     if residual is not None:
-        mr, cr, ldr = rows(residual)
+        pr, mr, cr, ldr, psr = xrows(residual)
         assert (mr, cr) == (m, c)
-    call("iswm_bn_apply", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(residual), ldr, _relu_code(relu), _p(out),
-         ldo, _stream())
+    call("iswm_bn_apply_pl", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(pr), ldr, psr, _relu_code(relu),
+         _p(po), ldo, pso, _stream())
     return out
 
 
 _BN_MASK_FROM_Y = os.environ.get("ISWM_BN_MASKY", "1") != "0"     # tuning switch
 
 
-def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_dres=False, dy=None):
-    """Returns (dy, dres|None); writes dgamma / dbeta (length-C fp32 tensors)."""
+def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_dres=False, dy=None, dy_planes=False):
+    """Returns (dy, dres|None); writes dgamma / dbeta (length-C fp32 tensors).  `out` (the saved activation, for the
+    ReLU pattern) may be Planes; dy is written as Planes when dy_planes (the conv's data / weight gradient kernels
+    take it pre-split)."""
     m, c, ldy = rows(y)
     _, _, ldd = rows(dout)
-    ldo = rows(out)[2] if out is not None else 0
+    po, ldo, pso = None, 0, 0
+    if out is not None:
+        po, _, _, ldo, pso = xrows(out)
     need = _lib.load().iswm_bn_bwd_workspace(m, c)
     ws = torch.empty((need // 8,), dtype=torch.float64, device=y.device)
     if dy is None:
-        dy = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        dy = new_planes(*y.shape, y.device) if dy_planes else torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    pdy, _, _, lddy, psdy = xrows(dy)
     dres = torch.empty(y.shape, dtype=torch.float32, device=y.device) if want_dres else None
     # ReLU without a residual: hand over the forward's scale / shift so the sign pattern is recomputed from y and the
     # saved output is never read (a residual stage's pattern depends on the identity tensor: read `out` there)
     masky = _relu_code(relu) == 1 and not want_dres and _BN_MASK_FROM_Y
-    call("iswm_bn_backward", _p(dout), ldd, _p(out), ldo, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
+    call("iswm_bn_backward_pl", _p(dout), ldd, _p(po), ldo, pso, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
          _p(coef[0]) if masky else None, _p(coef[1]) if masky else None,
-         _relu_code(relu), int(bool(training)), _p(dgamma), _p(dbeta), _p(dy), rows(dy)[2], _p(dres),
+         _relu_code(relu), int(bool(training)), _p(dgamma), _p(dbeta), _p(pdy), lddy, psdy, _p(dres),
          rows(dres)[2] if dres is not None else 0, _p(ws), need, _stream())
     return dy, dres
 
 
 def colsum(x):
     """per-channel sum over all pixels (bias gradient)"""
+    x = as_f32(x)
     partials, tiles, _ = colstat(x)
     c = x.shape[3]
     out = torch.empty((2, c), dtype=torch.float32, device=x.device)
@@ -406,13 +566,15 @@ def colsum(x):
     return out[0]
 
 
-def maxpool_fwd(x):
+def maxpool_fwd(x, planes=False):
+    x = as_f32(x)
     n, h, w, c, ld = geom(x)
     assert ld == c
     ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
-    y = new_act(n, ho, wo, c, x.device)
+    y = new_planes(n, ho, wo, c, x.device) if planes else new_act(n, ho, wo, c, x.device)
+    py, _, _, _, _, _, ps = xgeom(y)
     idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
-    call("iswm_maxpool3x3s2_fwd", _p(x), n, h, w, c, _p(y), _p(idx), ho, wo, _stream())
+    call("iswm_maxpool3x3s2_fwd_pl", _p(x), n, h, w, c, _p(py), ps, _p(idx), ho, wo, _stream())
     return y, idx
 
 
@@ -426,9 +588,9 @@ def maxpool_bwd(dy, idx, in_shape):
 
 
 def gap_fwd(x):
-    n, h, w, c, ld = geom(x)
+    px, n, h, w, c, ld, ps = xgeom(x)
     y = new_act(n, 1, 1, c, x.device)
-    call("iswm_gap_fwd", _p(x), n, h * w, c, ld, _p(y), _stream())
+    call("iswm_gap_fwd_pl", _p(px), ps, n, h * w, c, ld, _p(y), _stream())
     return y
 
 
@@ -439,8 +601,8 @@ def gap_bwd(dy, dx, accumulate):
 
 
 def bcast_fwd(v, out):
-    n, h, w, c, ld = geom(out)
-    call("iswm_bcast_fwd", _p(v), n, h * w, c, _p(out), ld, _stream())
+    po, n, h, w, c, ld, ps = xgeom(out)
+    call("iswm_bcast_fwd_pl", _p(as_f32(v)), n, h * w, c, _p(po), ld, ps, _stream())
     return out
 
 
@@ -452,11 +614,12 @@ def bcast_bwd(dy):
 
 
 def bilinear_fwd(x, ho, wo, out=None):
+    x = as_f32(x)
     n, hi, wi, c, ldx = geom(x)
     if out is None:
         out = new_act(n, ho, wo, c, x.device)
-    ldy = geom(out)[4]
-    call("iswm_bilinear_fwd", _p(x), n, hi, wi, c, ldx, _p(out), ho, wo, ldy, _stream())
+    po, _, _, _, _, ldy, ps = xgeom(out)
+    call("iswm_bilinear_fwd_pl", _p(x), n, hi, wi, c, ldx, _p(po), ps, ho, wo, ldy, _stream())
     return out
 
 
@@ -469,6 +632,7 @@ def bilinear_bwd(dy, hi, wi):
 
 def bilinear_to_nchw_fwd(x, c, ho, wo):
     """NHWC low-res logits (first c channels) -> NCHW [N,c,ho,wo]."""
+    x = as_f32(x)
     n, hi, wi, cp, ldx = geom(x)
     y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
     call("iswm_bilinear_nhwc_to_nchw_fwd", _p(x), n, hi, wi, c, ldx, _p(y), ho, wo, _stream())
@@ -494,6 +658,7 @@ def nchw_to_nhwc(x, cp=None):
 
 
 def nhwc_to_nchw(x, c=None):
+    x = as_f32(x)
     n, h, w, cc, ld = geom(x)
     c = c or cc
     y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
@@ -502,6 +667,7 @@ def nhwc_to_nchw(x, c=None):
 
 
 def copy_channels(src, dst):
+    src = as_f32(src)
     m, c, lds = rows(src)
     md, cd, ldd = rows(dst)
     assert (m, c) == (md, cd)
@@ -516,6 +682,7 @@ def add_inplace(dst, src):
 
 
 def dropout_fwd(x, p, seed, offset):
+    x = as_f32(x)
     assert x.is_contiguous()
     y = torch.empty_like(x)
     mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)

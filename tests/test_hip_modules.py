@@ -252,7 +252,14 @@ def test_whole_model(tag, backbone, os_):
     m.train()
     with record_masks(m, "") as rec:
         lg = m(x.to(dev()))
-    assert rel_err(lg, fx["train_logits"]) <= RTOL
+    # Train-mode BatchNorm over the 162 values per channel of the os8 case is ill-conditioned: the reference's own fp32
+    # result is 8.6e-4 away from the float64 evaluation of the same graph (tools/acc_check.py).  So every fp32
+    # evaluation is held to RTOL against FLOAT64, and two fp32 evaluations to the sum of their bounds.
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.no_grad():
+        ref64 = OracleDeepLab(cfg, sd64, dropout_p=0.0).train()(x.double())
+    assert rel_err(lg, ref64) <= RTOL
+    assert rel_err(lg, fx["train_logits"]) <= RTOL + rel_err(fx["train_logits"], ref64)
     w = torch.tensor([1.0, 3.0])
     loss = CrossEntropyLoss(weight=w, ignore_index=255)(lg, labels.to(dev()))
     assert rel_err(loss, fx["loss"]) <= RTOL

@@ -58,6 +58,10 @@ CASES = [  # n, h, w, cin, cout, k, stride, pad, dil
     (16, 129, 129, 256, 48, 1, 1, 0, 1),
     (16, 65, 65, 512, 1024, 1, 2, 0, 1),
     (16, 65, 65, 256, 256, 3, 2, 1, 1),
+    (16, 33, 33, 256, 256, 3, 1, 1, 1),
+    (16, 33, 33, 512, 512, 3, 1, 2, 2),
+    (16, 129, 129, 64, 64, 3, 1, 1, 1),
+    (16, 129, 129, 320, 256, 3, 1, 1, 1),
     (16, 33, 33, 2048, 256, 3, 1, 6, 6),
     (16, 33, 33, 2048, 256, 3, 1, 12, 12),
     (16, 33, 33, 2048, 256, 3, 1, 18, 18),
@@ -77,6 +81,31 @@ for (n, h, w, cin, cout, k, s, p, d) in (CASES[:NC_] if NC_ else CASES):
     g = ops.ConvGeom(x, cout, k, k, s, p, d)
     desc = g.desc(cin, cout)
     tag = g.tag()
+    if GEN == 2 and os.environ.get("PL_WGRAD", "1") != "0" and cin % 8 == 0 and cout % 8 == 0:
+        dy = torch.randn(n, g.ho, g.wo, cout, device=dev)
+        xp, dyp = split(x), split(dy)
+        dw_ref = torch.zeros(cout, k, k, cin, device=dev)
+        dw_new = torch.zeros_like(dw_ref)
+        need = lib.iswm_conv2d_wgrad_workspace(ctypes.byref(desc))
+        ws = torch.empty(max(need // 4, 4), device=dev)
+        need2 = lib.iswm_conv2d_wgrad_planes_workspace(ctypes.byref(desc))
+        ws2 = torch.empty(max(need2 // 4, 4), device=dev)
+        f_ref = lambda: call("iswm_conv2d_wgrad", ctypes.byref(desc), _p(x), _p(dy), _p(dw_ref), _p(ws), need, _stream())
+        f_new = lambda: call("iswm_conv2d_wgrad_planes", ctypes.byref(desc), _p(xp), xp.shape[1] * cin, _p(dyp), dyp.shape[1] * cout,
+                             _p(dw_new), _p(ws2), need2, _stream())
+        f_ref(); f_new()
+        torch.cuda.synchronize()
+        err = float((dw_ref - dw_new).abs().max() / dw_ref.abs().max())
+        for _ in range(3):
+            f_ref(); f_new()
+        r_med, _ = time_us(f_ref, ROUNDS)
+        n_med, _ = time_us(f_new, ROUNDS)
+        fl = g.flops()
+        print("%-34s wgrad err=%.1e  fp32-in %.1f us (%.0f TF)  planes %.1f us (%.0f TF)  x%.2f" %
+              (tag, err, r_med, fl / r_med * 1e-6, n_med, fl / n_med * 1e-6, r_med / n_med), flush=True)
+        assert err < 5e-6, "planes weight gradient differs"
+    if os.environ.get("PL_WGRAD_ONLY"):
+        continue
     for kind in (0, 1):
         nb = lib.iswm_conv2d_packed_weight_bytes(ctypes.byref(desc), kind)
         if nb == 0:
