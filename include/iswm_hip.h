@@ -94,7 +94,9 @@ int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const float* w, 
 /* Batched form: all conv weights of a model in ONE launch (a step otherwise issues two tiny pack kernels per conv).
  * jobs_dev is a DEVICE array sorted by first_block; job i owns workgroups [first_block, first_block +
  * iswm_pack_job_blocks(...)); total_blocks is the sum.  iswm_packed_weight_bytes is the buffer size for
- * (Cout, taps, Cin, kind), 0 if the gathered channel count (Cin forward, Cout data gradient) is not 32-aligned. */
+ * (Cout, taps, Cin, kind), 0 if the gathered channel count (Cin forward, Cout data gradient) is not 32-aligned.
+ * kind 2 / 3: forward / data-gradient weights in the fragment order of the planes kernels (iswm_conv2d_fwd_pl2 /
+ * iswm_conv2d_dgrad_pl2; gathered channel count a multiple of 64). */
 typedef struct iswm_pack_job {
     const float* w;         /* [Cout][taps][Cin] (OHWI) */
     void* packed;

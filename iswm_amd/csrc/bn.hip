@@ -6,6 +6,8 @@
 // thread mapping.  Statistics are reduced in two deterministic stages (per-tile partial
 // sums, then one double-precision pass over the tiles) -- no float atomics, so results
 // are bit-reproducible run to run.
+#include <stdlib.h>
+
 #include "rowmap.h"
 
 namespace iswm {
@@ -161,6 +163,42 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ y, i
             o.x = fminf(o.x, 6.f); o.y = fminf(o.y, 6.f); o.z = fminf(o.z, 6.f); o.w = fminf(o.w, 6.f);
         }
         st4x(out, r * ldo + c, ops, o);
+    }
+}
+
+// 8 channels per thread (two float4 of y, 16-byte plane stores): the form used whenever the output is pre-split
+template <int RELU, bool RES>
+__global__ __launch_bounds__(256) void k_bn_apply8(const float* __restrict__ y, int64_t M, int C8, int ldy,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   const float* __restrict__ mean, const void* __restrict__ res, int ldr,
+                                                   int64_t rps, void* __restrict__ out, int ldo, int64_t ops, int CQ, int RL) {
+    RowThread rt = row_thread(C8, CQ, RL);
+    if (!rt.active) return;
+    const int c = rt.c4 * 8;
+    const float4 sc0 = ld4(scale + c), sc1 = ld4(scale + c + 4), sh0 = ld4(shift + c), sh1 = ld4(shift + c + 4);
+    const float4 mu0 = ld4(mean + c), mu1 = ld4(mean + c + 4);
+    for (int64_t r = rt.row0; r < M; r += rt.rstep) {
+        const float4 v0 = ld4(y + r * ldy + c), v1 = ld4(y + r * ldy + c + 4);
+        float4 o0, o1;
+        o0.x = (v0.x - mu0.x) * sc0.x + sh0.x; o0.y = (v0.y - mu0.y) * sc0.y + sh0.y;
+        o0.z = (v0.z - mu0.z) * sc0.z + sh0.z; o0.w = (v0.w - mu0.w) * sc0.w + sh0.w;
+        o1.x = (v1.x - mu1.x) * sc1.x + sh1.x; o1.y = (v1.y - mu1.y) * sc1.y + sh1.y;
+        o1.z = (v1.z - mu1.z) * sc1.z + sh1.z; o1.w = (v1.w - mu1.w) * sc1.w + sh1.w;
+        if (RES) {
+            float4 q0, q1;
+            ld8x(res, r * ldr + c, rps, q0, q1);
+            o0.x += q0.x; o0.y += q0.y; o0.z += q0.z; o0.w += q0.w;
+            o1.x += q1.x; o1.y += q1.y; o1.z += q1.z; o1.w += q1.w;
+        }
+        if (RELU) {
+            o0.x = fmaxf(o0.x, 0.f); o0.y = fmaxf(o0.y, 0.f); o0.z = fmaxf(o0.z, 0.f); o0.w = fmaxf(o0.w, 0.f);
+            o1.x = fmaxf(o1.x, 0.f); o1.y = fmaxf(o1.y, 0.f); o1.z = fmaxf(o1.z, 0.f); o1.w = fmaxf(o1.w, 0.f);
+        }
+        if (RELU == 2) {
+            o0.x = fminf(o0.x, 6.f); o0.y = fminf(o0.y, 6.f); o0.z = fminf(o0.z, 6.f); o0.w = fminf(o0.w, 6.f);
+            o1.x = fminf(o1.x, 6.f); o1.y = fminf(o1.y, 6.f); o1.z = fminf(o1.z, 6.f); o1.w = fminf(o1.w, 6.f);
+        }
+        st8x(out, r * ldo + c, ops, o0, o1);
     }
 }
 
@@ -444,9 +482,26 @@ extern "C" int iswm_bn_apply_pl(const float* y, int64_t M, int C, int ldy, const
     if (int e = chk_ps("bn_apply(out)", out, M, ldo, out_ps)) return e;
     if (residual) if (int e = chk_ps("bn_apply(residual)", residual, M, ldr, res_ps)) return e;
     const int64_t rps = res_ps, ops = out_ps;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_ps != 0 && C % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && aligned16(out) && (out_ps < 0 || out_ps % 8 == 0) &&
+        (!residual || (ldr % 8 == 0 && aligned16(residual) && (res_ps <= 0 || res_ps % 8 == 0)))) {
+        RowPlan p = plan_rows(M, C / 2);       // C / 8 groups of 8 channels
+        dim3 grid(p.rowblocks, p.colblocks), blk(256);
+#define LAUNCH8(R, S) \
+    hipLaunchKernelGGL((k_bn_apply8<R, S>), grid, blk, 0, s, y, M, p.C4, ldy, scale, shift, mean, residual, ldr, rps, out, \
+                       ldo, ops, p.CQ, p.RL)
+        ISWM_REQUIRE(relu == 0 || relu == 1 || relu == 6, "bn_apply: relu must be 0 (none), 1 (ReLU) or 6 (ReLU6)");
+        if (relu == 6 && residual) LAUNCH8(2, true);
+        else if (relu == 6) LAUNCH8(2, false);
+        else if (relu && residual) LAUNCH8(1, true);
+        else if (relu) LAUNCH8(1, false);
+        else if (residual) LAUNCH8(0, true);
+        else LAUNCH8(0, false);
+#undef LAUNCH8
+        return check_launch("bn_apply8");
+    }
     RowPlan p = plan_rows(M, C);
     dim3 grid(p.rowblocks, p.colblocks), blk(256);
-    hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(R, S) \
     hipLaunchKernelGGL((k_bn_apply<R, S>), grid, blk, 0, s, y, M, p.C4, ldy, scale, shift, mean, residual, ldr, rps, out, \
                        ldo, ops, \
@@ -526,9 +581,11 @@ extern "C" int iswm_bn_backward_pl(const float* dout, int ldd, const void* out, 
         hipLaunchKernelGGL((k_bn_bwd_finalize<double, 16>), dim3((C + 15) / 16), dim3(256), 0, s, partials, tiles, C,
                            dgamma, dbeta, sums);
     if (int e = check_launch("bn_bwd_finalize")) return e;
+    const double inv = 1.0 / (double)M;
+    // (an 8-channel form of the backward apply pass -- 16-byte plane stores -- measured 1.7 ms/step SLOWER: its double-precision
+    // per-channel coefficients cost the occupancy the wider stores buy)
     RowPlan p = plan_rows(M, C);
     dim3 grid(p.rowblocks, p.colblocks), blk(256);
-    const double inv = 1.0 / (double)M;
 #define LAUNCH(R, T, D)                                                                                          \
     hipLaunchKernelGGL((k_bn_bwd_apply<R, T, D>), grid, blk, 0, s, dout, ldd, out, ldo, ops, y, ldy, M, p.C4, C, mean,    \
                        invstd, gamma, mask_scale, mask_shift, sums, inv, dy, lddy, dyps, dres, lddres, p.CQ, p.RL)

@@ -86,7 +86,42 @@ void launch_join_planes(const unsigned short* in, int ldp, int64_t ps, int64_t M
 void launch_split_planes(const float* x, int64_t M, int C, int ldx, unsigned short* out, int ldp, int64_t pstride_elems,
                          int planes, hipStream_t s);
 
+
+// Weight packing for k_conv_pl2 (16x16x32 fragments): packed[((cb * K32 + k32) * NP + plane) * 64 + lane] (uint4) holds, for
+// column cb*16 + (lane & 15), the 8 bf16 of that plane at k = k32*32 + 8*(lane >> 4) .. +7.
+//   fwd  : column = cout, k = (tap, cin);   dgrad: column = cin, k = (tap, cout) (implicit transpose).
+// Columns >= NC are zero; cb runs to ceil(NC/128)*8.
+template <bool DGRAD, int NP>
+__device__ __forceinline__ void pack_weights_pl2_body(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int T,
+                                                      int Cin, int K32, int idx) {
+    const int lane = idx & 63, f = idx >> 6;
+    const int k32 = f % K32, cb = f / K32;
+    const int col = cb * 16 + (lane & 15), k0 = k32 * 32 + 8 * (lane >> 4);
+    const int NC = DGRAD ? Cin : Cout, GC = DGRAD ? Cout : Cin;
+    float v[8];
+    const int tap = k0 / GC, g0 = k0 - tap * GC;      // 8 consecutive k never straddle a tap (GC % 64 == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x = 0.f;
+        if (col < NC) x = DGRAD ? w[((size_t)(g0 + i) * T + tap) * Cin + col] : w[((size_t)col * T + tap) * Cin + g0 + i];
+        v[i] = x;
+    }
+    uint4* o = packed + (size_t)f * (64 * NP) + lane;
+    if constexpr (NP == 1) {
+        const uint2 r0 = round_bf16x4(make_float4(v[0], v[1], v[2], v[3])), r1 = round_bf16x4(make_float4(v[4], v[5], v[6], v[7]));
+        o[0] = make_uint4(r0.x, r0.y, r1.x, r1.y);
+    } else {
+        uint2 h0, m0, l0, h1, m1, l1;
+        split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+        split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
 // second-generation planes kernel: (16*rbw) x 128 tiles, one workgroup per CU (conv_mfma_pl2.hip)
+int pack_job_blocks_pl2(int Cout, int T, int Cin, bool dgrad);
 int conv_pl2_pick_rbw(int64_t M, int cols);
 bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw);
 size_t packed_weight_bytes_pl2(int Cout, int T, int Cin, bool dgrad, int planes);

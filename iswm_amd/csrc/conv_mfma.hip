@@ -1004,12 +1004,18 @@ extern "C" int iswm_conv2d_pack_weights(const iswm_conv_desc* d, int kind, const
 
 /* ---- batched packing: every conv of a model in one launch ---- */
 extern "C" size_t iswm_packed_weight_bytes(int Cout, int taps, int Cin, int kind) {
-    if (Cout <= 0 || taps <= 0 || Cin <= 0 || (kind != 0 && kind != 1) || (kind ? Cout : Cin) % 32 != 0) return 0;
+    if (Cout <= 0 || taps <= 0 || Cin <= 0 || kind < 0 || kind > 3 || conv_math() < 1) return 0;
+    if (kind >= 2) {        // planes kernels: gathered channel count a multiple of 64
+        if (((kind == 3) ? Cout : Cin) % 64 != 0) return 0;
+        return packed_weight_bytes_pl2(Cout, taps, Cin, kind == 3, math_planes());
+    }
+    if ((kind ? Cout : Cin) % 32 != 0) return 0;
     return packed_weight_bytes_x6(Cout, taps, Cin, kind == 1, math_planes());
 }
 
 extern "C" int iswm_pack_job_blocks(int Cout, int taps, int Cin, int kind) {
     if (iswm_packed_weight_bytes(Cout, taps, Cin, kind) == 0) return 0;
+    if (kind >= 2) return pack_job_blocks_pl2(Cout, taps, Cin, kind == 3);
     return pack_job_blocks_x6(Cout, taps, Cin, kind == 1);
 }
 

@@ -462,30 +462,13 @@ __global__ __launch_bounds__(256) void k_pack_weights_pl2(const float* __restric
                                                           int T, int Cin, int K32, int total) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int lane = idx & 63, f = idx >> 6;
-    const int k32 = f % K32, cb = f / K32;
-    const int col = cb * 16 + (lane & 15), k0 = k32 * 32 + 8 * (lane >> 4);
-    const int NC = DGRAD ? Cin : Cout, GC = DGRAD ? Cout : Cin;
-    float v[8];
-    const int tap = k0 / GC, g0 = k0 - tap * GC;      // 8 consecutive k never straddle a tap (GC % 64 == 0)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float x = 0.f;
-        if (col < NC) x = DGRAD ? w[((size_t)(g0 + i) * T + tap) * Cin + col] : w[((size_t)col * T + tap) * Cin + g0 + i];
-        v[i] = x;
-    }
-    uint4* o = packed + (size_t)f * (64 * NP) + lane;
-    if constexpr (NP == 1) {
-        const uint2 r0 = round_bf16x4(make_float4(v[0], v[1], v[2], v[3])), r1 = round_bf16x4(make_float4(v[4], v[5], v[6], v[7]));
-        o[0] = make_uint4(r0.x, r0.y, r1.x, r1.y);
-    } else {
-        uint2 h0, m0, l0, h1, m1, l1;
-        split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-        split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        o[64] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-        o[128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    }
+    pack_weights_pl2_body<DGRAD, NP>(w, packed, Cout, T, Cin, K32, idx);
+}
+
+int pack_job_blocks_pl2(int Cout, int T, int Cin, bool dgrad) {
+    const int NC = dgrad ? Cin : Cout, GC = dgrad ? Cout : Cin;
+    const long long total = (long long)((NC + 127) / 128) * 8 * (T * GC / 32) * 64;
+    return (int)((total + 255) / 256);
 }
 
 size_t packed_weight_bytes_pl2(int Cout, int T, int Cin, bool dgrad, int planes) {

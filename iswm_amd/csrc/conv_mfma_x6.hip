@@ -463,9 +463,18 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const PackJob* __res
         else hi = mid - 1;
     }
     const PackJob j = jobs[lo];
+    const int idx = (b - j.first_block) * 256 + threadIdx.x;
+    if (j.kind >= 2) {          // kinds 2 / 3: the 16x16x32 fragment order of the planes kernels (conv_mfma_pl2.hip)
+        const bool dg = j.kind == 3;
+        const int NC = dg ? j.Cin : j.Cout, GC = dg ? j.Cout : j.Cin;
+        const int cbs = ((NC + 127) / 128) * 8, K32 = j.T * GC / 32;
+        if (idx >= cbs * K32 * 64) return;
+        if (dg) pack_weights_pl2_body<true, NP>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K32, idx);
+        else pack_weights_pl2_body<false, NP>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K32, idx);
+        return;
+    }
     const int NC = j.kind ? j.Cin : j.Cout, GC = j.kind ? j.Cout : j.Cin;
     const int cbs = ((NC + 63) / 64) * 2, K16 = j.T * GC / 16;
-    const int idx = (b - j.first_block) * 256 + threadIdx.x;
     if (idx >= cbs * K16 * 64) return;
     if (j.kind) pack_weights_body<true, NP>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);
     else pack_weights_body<false, NP>(j.w, (uint4*)j.packed, j.Cout, j.T, j.Cin, K16, idx);

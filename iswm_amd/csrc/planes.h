@@ -78,6 +78,60 @@ __device__ __forceinline__ void st4x(void* base, int64_t off, int64_t ps, float4
     }
 }
 
+// 8 consecutive channels (channel % 8 == 0, 16-byte plane accesses: the memory-bound passes run ~1.3x faster than with 8-byte ones)
+__device__ __forceinline__ void ld8x(const void* base, int64_t off, int64_t ps, float4& a, float4& b) {
+    if (ps == 0) {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+        a = p[0];
+        b = p[1];
+        return;
+    }
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + off;
+    const uint4 h = *reinterpret_cast<const uint4*>(p);
+    a = bf16x4_to_f32(make_uint2(h.x, h.y));
+    b = bf16x4_to_f32(make_uint2(h.z, h.w));
+    if (ps > 0) {
+        const uint4 m = *reinterpret_cast<const uint4*>(p + ps), l = *reinterpret_cast<const uint4*>(p + 2 * ps);
+        const float4 ma = bf16x4_to_f32(make_uint2(m.x, m.y)), mb = bf16x4_to_f32(make_uint2(m.z, m.w));
+        const float4 la = bf16x4_to_f32(make_uint2(l.x, l.y)), lb = bf16x4_to_f32(make_uint2(l.z, l.w));
+        a.x = (a.x + ma.x) + la.x; a.y = (a.y + ma.y) + la.y; a.z = (a.z + ma.z) + la.z; a.w = (a.w + ma.w) + la.w;
+        b.x = (b.x + mb.x) + lb.x; b.y = (b.y + mb.y) + lb.y; b.z = (b.z + mb.z) + lb.z; b.w = (b.w + mb.w) + lb.w;
+    }
+}
+
+__device__ __forceinline__ void st8x(void* base, int64_t off, int64_t ps, float4 a, float4 b) {
+    if (ps == 0) {
+        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off);
+        p[0] = a;
+        p[1] = b;
+        return;
+    }
+    unsigned short* p = reinterpret_cast<unsigned short*>(base) + off;
+    if (ps > 0) {
+        uint2 h0, m0, l0, h1, m1, l1;
+        split3(a, h0, m0, l0);
+        split3(b, h1, m1, l1);
+        *reinterpret_cast<uint4*>(p) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(p + ps) = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        *reinterpret_cast<uint4*>(p + 2 * ps) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else {
+        const uint2 r0 = round_bf16x4(a), r1 = round_bf16x4(b);
+        *reinterpret_cast<uint4*>(p) = make_uint4(r0.x, r0.y, r1.x, r1.y);
+    }
+}
+
+__device__ __forceinline__ void ld8x_hi(const void* base, int64_t off, int64_t ps, float4& a, float4& b) {
+    if (ps == 0) {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+        a = p[0];
+        b = p[1];
+        return;
+    }
+    const uint4 h = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + off);
+    a = bf16x4_to_f32(make_uint2(h.x, h.y));
+    b = bf16x4_to_f32(make_uint2(h.z, h.w));
+}
+
 // the hi plane alone (sign / range tests on a saved activation): truncation keeps sign and x > 0, x < 6 for x in [0, 6]
 __device__ __forceinline__ float4 ld4x_hi(const void* base, int64_t off, int64_t ps) {
     if (ps == 0) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);

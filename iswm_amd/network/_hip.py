@@ -462,7 +462,15 @@ class WeightPacker(object):
                 continue
             taps = m.kernel_size[0] * m.kernel_size[1]
             bufs = {}
+            # with pre-split activations the planes kernels take the conv (kinds 2 / 3); the fp32-input fragment order
+            # (kinds 0 / 1) is packed only for the direction the planes kernels do not cover
+            kinds = []
             for kind in (0, 1):
+                if ops.planes_on() and lib.iswm_packed_weight_bytes(m.out_channels, taps, m.in_channels, kind + 2):
+                    kinds.append(kind + 2)
+                else:
+                    kinds.append(kind)
+            for kind in kinds:
                 nb = lib.iswm_packed_weight_bytes(m.out_channels, taps, m.in_channels, kind)
                 if nb == 0:
                     continue
@@ -471,7 +479,7 @@ class WeightPacker(object):
                 jobs.append((w.data_ptr(), buf.data_ptr(), m.out_channels, taps, m.in_channels, kind, first, 0))
                 first += lib.iswm_pack_job_blocks(m.out_channels, taps, m.in_channels, kind)
             if bufs:
-                e = dict(live=False, epoch=-1, version=-1, ptr=w.data_ptr(), buf={0: bufs.get(0), 1: bufs.get(1)})
+                e = dict(live=False, epoch=-1, version=-1, ptr=w.data_ptr(), buf={k: bufs.get(k) for k in range(4)})
                 m._iswm_wpk = e
                 entries.append((m, e))
                 keep.append(bufs)
@@ -491,7 +499,7 @@ class WeightPacker(object):
         math = _lib.load().iswm_get_conv_math()
         if math < 1 or not ops._USE_PACKED or not self.convs or not _BATCH_PACK:
             return
-        key = (math,) + tuple(m.weight.data_ptr() for m in self.convs)      # bf16x6 packs 3 planes, bf16 one
+        key = (math, ops.planes_on()) + tuple(m.weight.data_ptr() for m in self.convs)      # bf16x6 packs 3 planes, bf16 one
         if key != self.key:
             self._build(self.convs[0].weight.device)
             self.key = key

@@ -78,15 +78,54 @@ class _FusedBase(torch.optim.Optimizer):
             raise NotImplementedError("one parameter group (as train.py:424 passes model.parameters())")
         self.arena = arena_of(self.param_groups[0]["params"])
         dev = self.arena.data.device
-        self._hyper_host = torch.zeros(4, dtype=torch.float32)
+        # step hyper-parameters (lr, Adam bias corrections) reach the kernel through device memory so that the launch stays
+        # capturable; the pinned staging area is a RING of slots, each guarded by the event of the copy that last read it:
+        # the DMA reads pinned memory when the GPU gets to it, not at enqueue, and the host runs steps ahead of the GPU
+        self._nslots = 8
+        self._hyper_host = torch.zeros((self._nslots, 4), dtype=torch.float32)
         if dev.type == "cuda":
             self._hyper_host = self._hyper_host.pin_memory()
+        self._hyper_events = [None] * self._nslots
+        self._hyper_slot = 0
         self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=dev)
 
     def _push_hyper(self, *vals):
-        for i, v in enumerate(vals):
-            self._hyper_host[i] = v
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        i = self._hyper_slot
+        self._hyper_slot = (i + 1) % self._nslots
+        ev = self._hyper_events[i]
+        if ev is not None:
+            ev.synchronize()                   # the copy that read this slot nslots steps ago has run
+        for k, v in enumerate(vals):
+            self._hyper_host[i, k] = v
+        self._hyper_dev.copy_(self._hyper_host[i], non_blocking=True)
+        if self._hyper_dev.is_cuda:
+            ev = ev or torch.cuda.Event()
+            ev.record()
+            self._hyper_events[i] = ev
+
+    def _segments(self):
+        """[(start, end)) element ranges of the arena to update: torch.optim skips parameters without a gradient (frozen
+        layers keep their weights, momentum and moments untouched), so only runs of parameters that have one are stepped"""
+        a = self.arena
+        segs, start = [], None
+        for i, p in enumerate(a.params):
+            live = p.grad is not None
+            if live and start is None:
+                start = a.offsets[i]
+            if not live and start is not None:
+                segs.append((start, a.offsets[i]))
+                start = None
+        if start is not None:
+            segs.append((start, a.numel))
+        return segs
+
+    def load_state_dict(self, state_dict):
+        """accepts the state of the stock torch optimizer of the same family (the reference's checkpoints,
+        train.py:567-582): its param_groups lack this class's own keys"""
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            for k, v in self.defaults.items():
+                g.setdefault(k, v)
 
     def zero_grad(self, set_to_none=True):
         self.arena.zero_grad()
@@ -121,8 +160,9 @@ class FusedSGD(_FusedBase):
         g = self.param_groups[0]
         self._grads_ready()
         self._push_hyper(g["lr"])
-        ops.sgd_step(self.arena.data, self.arena.grad, self._buf, self._hyper_dev, g["momentum"],
-                     g["weight_decay"], g["nesterov"])
+        for a, b in self._segments():
+            ops.sgd_step(self.arena.data[a:b], self.arena.grad[a:b], self._buf[a:b], self._hyper_dev, g["momentum"],
+                         g["weight_decay"], g["nesterov"])
         ops.weights_changed()
         return loss
 
@@ -159,8 +199,9 @@ class FusedAdam(_FusedBase):
         self._t += 1
         b1, b2 = g["betas"]
         self._push_hyper(g["lr"], 1.0 - b1 ** self._t, 1.0 - b2 ** self._t)
-        ops.adam_step(self.arena.data, self.arena.grad, self._m, self._v, self._hyper_dev, b1, b2, g["eps"],
-                      g["weight_decay"], g["decoupled"])
+        for a, b in self._segments():
+            ops.adam_step(self.arena.data[a:b], self.arena.grad[a:b], self._m[a:b], self._v[a:b], self._hyper_dev, b1, b2,
+                          g["eps"], g["weight_decay"], g["decoupled"])
         ops.weights_changed()
         for p in self.arena.params:
             self.state[p]["step"] += 1

@@ -19,6 +19,8 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets default to 32 MB s
 ring step moves a few MB per link -- large enough to run at link rate, small enough that
 the first bucket starts within a few ms of backward starting.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -62,14 +64,28 @@ class DistributedDataParallelHIP(nn.Module):
                 self._need[self.bucket_of[id(p)]] += 1
         self._left = list(self._need)
         self._works = []
+        self._sync = True
+        # diagnostics for bench.py: what was all-reduced and how long the compute stream stood still for it
+        self.stats = dict(bytes_allreduced=0, allreduces=0, steps=0, exposed_wait_ms=0.0)
+        self._wait_events = []
         module._iswm_on_ready = self._on_ready
 
     def forward(self, *args, **kwargs):
         self._left = list(self._need)
         return self.module(*args, **kwargs)
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """gradient accumulation: backward passes inside this context only accumulate locally; the first backward outside
+        it all-reduces the accumulated sum (same contract as torch's DistributedDataParallel.no_sync)"""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
     def _on_ready(self, p):
-        if self.world == 1:
+        if self.world == 1 or not self._sync:
             return
         b = self.bucket_of[id(p)]
         self._left[b] -= 1
@@ -77,13 +93,37 @@ class DistributedDataParallelHIP(nn.Module):
             s, e = self.buckets[b]
             self._works.append(dist.all_reduce(self.arena.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
+            self.stats["bytes_allreduced"] += (e - s) * 4
+            self.stats["allreduces"] += 1
 
     def finish_grad_sync(self):
         """Block the compute stream until every bucket's all-reduce has landed (call before
         optimizer.step(); ``attach`` does it automatically)."""
+        timed = bool(self._works) and self.arena.grad.is_cuda
+        if timed:
+            a = torch.cuda.Event(enable_timing=True)
+            a.record()
         for w in self._works:
             w.wait()
+        if timed:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self._wait_events.append((a, b))
+        if self._works:
+            self.stats["steps"] += 1
         self._works = []
+
+    def comm_stats(self):
+        """totals since construction (call after a device synchronize): bytes and all-reduce launches, and the time the
+        compute stream spent between reaching the optimizer step and the last bucket landing (exposed, not overlapped)"""
+        for a, b in self._wait_events:
+            self.stats["exposed_wait_ms"] += a.elapsed_time(b)
+        self._wait_events = []
+        out = dict(self.stats)
+        out["buckets"] = len(self.buckets)
+        out["backend"] = dist.get_backend(self.group) if dist.is_initialized() else "none"
+        out["world_size"] = self.world
+        return out
 
     def attach(self, optimizer):
         optimizer.register_step_pre_hook(lambda *a, **k: self.finish_grad_sync())

@@ -33,7 +33,7 @@ from torch.utils import data
 from . import network, ops
 from .optim import FusedAdam, FusedAdamW, FusedSGD
 from .parallel import DistributedDataParallelHIP
-from .utils.loss import CrossEntropyLoss
+from .utils.loss import CrossEntropyLoss, calculate_class_weights
 
 
 def get_argparser():
@@ -121,14 +121,34 @@ def get_dataset(opts):
                                         seed=opts.random_seed))
 
 
-def calculate_class_weights(loader):
-    """train.py:388-410"""
-    black = white = 0
-    for batch in loader:
-        labels = batch['mask'] if isinstance(batch, dict) else batch[1]
-        black += (labels == 0).sum().item()
-        white += (labels == 1).sum().item()
-    return torch.FloatTensor([1.0, np.sqrt(black / white)])
+def load_checkpoint(path):
+    """torch.load that executes nothing from the file; the reference's checkpoints (train.py:567-582) carry numpy
+    scalars inside val_score / best_score, which the weights-only unpickler admits once their types are allow-listed"""
+    allow = [np.core.multiarray.scalar if hasattr(np, "core") else None, np.dtype, np.float64, np.float32, np.int64]
+    try:
+        from numpy import dtypes as _npd
+        allow += [getattr(_npd, n) for n in ("Float64DType", "Float32DType", "Int64DType") if hasattr(_npd, n)]
+    except ImportError:
+        pass
+    allow = [a for a in allow if a is not None]
+    try:
+        with torch.serialization.safe_globals(allow):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:                      # still refused: keep the tensors, drop the score dictionaries
+        raise RuntimeError("checkpoint %s cannot be read with the weights-only loader: %s" % (path, e))
+
+
+def scalar_score(v, weighted=None):
+    """best_score as this loop keeps it (one float).  The reference stores a dictionary of per-metric bests
+    (update_best_score, train.py:799-811) next to the checkpoint's own `weighted_score` (train.py:567-582): a resumed
+    run compares against that weighted score."""
+    if isinstance(v, dict):
+        if weighted is not None:
+            return float(weighted)
+        if "Foreground IoU" in v and "Foreground F1" in v:
+            return 0.5 * float(v["Foreground IoU"]) + 0.5 * float(v["Foreground F1"])
+        return -1.0
+    return float(v)
 
 
 def setup_model(opts):
@@ -208,6 +228,8 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    # model initialisation is seeded identically on every rank (and broadcast anyway); the augmentation draws
+    # (Python `random`) and the dropout masks (torch's initial seed feeds the Philox counter) must differ per rank
     torch.manual_seed(opts.random_seed)
     np.random.seed(opts.random_seed)
     random.seed(opts.random_seed)
@@ -229,7 +251,7 @@ def main(argv=None):
     train_loader = data.DataLoader(train_dst, batch_size=opts.batch_size, shuffle=sampler is None, sampler=sampler,
                                    num_workers=opts.num_workers, drop_last=True)
     val_loader = data.DataLoader(val_dst, batch_size=opts.val_batch_size, shuffle=False, num_workers=0)
-    class_weights = calculate_class_weights(train_loader).to(device)
+    class_weights = calculate_class_weights(train_loader, dist.group.WORLD if world > 1 else None).to(device)
     if rank == 0:
         print("Class weights - Black: %.4f, White: %.4f" % (class_weights[0], class_weights[1]))
 
@@ -237,15 +259,18 @@ def main(argv=None):
     cur_itrs, best_score = 0, -1.0
     ckpt = None
     if opts.ckpt is not None and os.path.isfile(opts.ckpt):
-        ckpt = torch.load(opts.ckpt, map_location='cpu', weights_only=True)
+        ckpt = load_checkpoint(opts.ckpt)
         state = {(k[7:] if k.startswith('module.') else k): v for k, v in ckpt["model_state"].items()}
         ret = model.load_state_dict(state, strict=False)
         print("Model restored from %s (missing %d, unexpected %d)" % (opts.ckpt, len(ret.missing_keys),
                                                                      len(ret.unexpected_keys)))
         if opts.continue_training:
             cur_itrs = ckpt["cur_itrs"]
-            best_score = ckpt.get("best_score", best_score)
+            best_score = scalar_score(ckpt.get("best_score", best_score), ckpt.get("weighted_score"))
     model.to(device)
+    if world > 1:
+        torch.manual_seed(opts.random_seed + 1000003 * rank)       # dropout / augmentation streams differ per rank from here on
+        random.seed(opts.random_seed + 1000003 * rank)
     optimizer = setup_optimizer(model, opts)
     scheduler = setup_scheduler(optimizer, opts)
     group = dist.group.WORLD if world > 1 else None
@@ -291,6 +316,8 @@ def main(argv=None):
                       (cur_epochs, cur_itrs, opts.total_itrs, avg, optimizer.param_groups[0]['lr'], n_last / dt))
                 interval_loss.zero_()
                 t_last, n_last = time.time(), 0
+            if cur_itrs % opts.val_interval == 0 and world > 1:
+                dist.barrier()               # the other ranks wait HERE (not inside the next step's all-reduce) while rank 0 validates
             if cur_itrs % opts.val_interval == 0 and rank == 0:
                 score = validate(model, val_loader, device, opts)
                 weighted = 0.5 * score["Foreground IoU"] + 0.5 * score["Foreground F1"]
@@ -299,6 +326,8 @@ def main(argv=None):
                     best_score = weighted
                     print("saved", save_best_model(model, optimizer, scheduler, opts, score, weighted, cur_itrs,
                                                    best_score))
+            if cur_itrs % opts.val_interval == 0 and world > 1:
+                dist.barrier()
             scheduler.step()
             if cur_itrs >= opts.total_itrs:
                 break

@@ -97,11 +97,24 @@ def create_loss(loss_type="focal", temporal_loss="none", temporal_weight=0.5, **
     return FocalLoss(**kwargs)
 
 
-def calculate_class_weights(loader):
-    """[1, sqrt(N_black / N_white)] over one pass of the loader -- train.py:388-410."""
+def calculate_class_weights(loader, group=None):
+    """[1, sqrt(N_black / N_white)] over one pass of the loader -- train.py:388-410.
+
+    Under data parallelism every rank iterates its own shard of the train set (DistributedSampler); the reference counts
+    the WHOLE set, and the criterion's global normaliser assumes one common weight vector, so the two pixel counts are
+    summed over the process group (int64 all-reduce) before the ratio is taken: every rank gets the same weights."""
     black = white = 0
     for batch in loader:
         labels = batch['mask'] if isinstance(batch, dict) else batch[1]
         black += int((labels == 0).sum())
         white += int((labels == 1).sum())
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            cnt = torch.tensor([black, white], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+            black, white = int(cnt[0]), int(cnt[1])
+    except ImportError:
+        pass
     return torch.tensor([1.0, math.sqrt(black / white)], dtype=torch.float32)

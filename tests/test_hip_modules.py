@@ -744,17 +744,18 @@ def test_whole_model_odd_sizes(os_, n, h, w):
 
 
 def test_fix_bn_training_step():
-    """utils.fix_bn (utils/utils.py:30-33): BatchNorm layers frozen in eval mode while the model trains -- the fused
+    """utils.fix_bn of the reference (utils/utils.py:30-33): BatchNorm layers frozen in eval mode while the model trains -- the fused
     stage normalises with the running statistics, leaves them untouched, and its backward is the eval-mode one.  Logits,
     loss and every gradient vs the oracle evaluated the same way (its eval mode, dropout off)."""
-    from iswm_amd.utils import fix_bn
     from iswm_amd.utils.loss import CrossEntropyLoss
     from oracle import loss as oloss
     from oracle.deeplab import OracleDeepLab
     from oracle.synth import synth_images, synth_labels
     m, cfg, sd = _build("resnet50", 16)
     m.train()
-    fix_bn(m)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
     x = synth_images(4, 65, 65, seed=61)
     lab = synth_labels(4, 65, 65, seed=61, p_fg=0.2)
     with record_masks(m, "") as rec:

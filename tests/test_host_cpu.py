@@ -188,49 +188,145 @@ def test_c_abi_argument_validation_without_a_gpu():
         lib.iswm_set_conv_math(old)
 
 
-def test_poly_lr_matches_reference_scheduler():
-    """utils/scheduler.py:3-11 (importable standalone) vs iswm_amd.utils.PolyLR on the fused optimizer's host side"""
-    import importlib.util
-    ref_path = "/root/reference/utils/scheduler.py"
-    from iswm_amd.utils import PolyLR
-    p = torch.nn.Parameter(torch.zeros(3))
-    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9)
-    sch = PolyLR(opt, max_iters=50, power=0.9)
-    got = []
-    for _ in range(50):                          # (past max_iters the reference's formula leaves the reals; so does this)
-        opt.step()
-        sch.step()
-        got.append(opt.param_groups[0]["lr"])
-    want = [max(0.01 * (1 - t / 50) ** 0.9, 1e-6) for t in range(1, 51)]
-    for t, (g, w) in enumerate(zip(got, want)):
-        assert abs(g - w) <= 1e-12, (t, g, w)
-    assert got[-1] == 1e-6                       # min_lr floor at the last iteration
-    if os.path.exists(ref_path):                 # in the build container: the reference's own class, step for step
-        spec = importlib.util.spec_from_file_location("ref_sched", ref_path)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        q = torch.nn.Parameter(torch.zeros(3))
-        opt2 = torch.optim.SGD([q], lr=0.01, momentum=0.9)
-        sch2 = mod.PolyLR(opt2, max_iters=50, power=0.9)
-        for t in range(45):
-            opt2.step()
-            sch2.step()
-            assert opt2.param_groups[0]["lr"] == got[t]
+def test_calculate_class_weights_matches_oracle():
+    """the product's calculate_class_weights (train.py:388-410) on a loader of (image, label) batches and on dict
+    batches, against the oracle's restatement of the same formula"""
+    from iswm_amd.utils.loss import calculate_class_weights
+    from oracle import loss as oloss
+    g = torch.Generator().manual_seed(5)
+    labs = [(torch.rand(3, 17, 19, generator=g) < 0.13).to(torch.uint8) for _ in range(4)]
+    labs[1][0, :3] = 255                                           # ignored pixels count for neither class
+    want = oloss.class_weights(torch.cat([x.reshape(-1) for x in labs]))
+    got = calculate_class_weights([(torch.zeros(3), x) for x in labs])
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    assert torch.equal(calculate_class_weights([{"mask": x} for x in labs]), want)
 
 
-def test_small_utils():
-    """utils/utils.py:6-38: denormalize undoes ExtNormalize; set_bn_momentum / fix_bn touch every BatchNorm2d"""
-    import numpy as np
-    from iswm_amd.network import modeling
-    from iswm_amd.utils import Denormalize, denormalize, fix_bn, set_bn_momentum
-    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
-    img = torch.rand(3, 5, 7)
-    norm = (img - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
-    assert torch.allclose(denormalize(norm, mean, std), img, atol=1e-6)
-    assert torch.allclose(Denormalize(mean, std)(norm), img, atol=1e-6)
-    assert np.allclose(Denormalize(mean, std)(norm.numpy()), img.numpy(), atol=1e-6)
-    m = modeling.deeplabv3plus_resnet50(num_classes=2, output_stride=16).train()
-    set_bn_momentum(m, 0.01)
-    fix_bn(m)
-    bns = [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d)]
-    assert len(bns) == 62 and all(b.momentum == 0.01 and not b.training for b in bns) and m.training
+def _cw_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iswm_amd.utils.loss import calculate_class_weights
+    g = torch.Generator().manual_seed(11)
+    full = [(torch.rand(2, 16, 16, generator=g) < (0.05 + 0.1 * i)).to(torch.uint8) for i in range(6)]
+    shard = full[rank::world]                                      # what a DistributedSampler hands this rank
+    q.put((rank, calculate_class_weights([(None, x) for x in shard]), calculate_class_weights.__module__))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_class_weights_are_global_under_data_parallelism():
+    """every rank iterates its own shard but must end up with the weights of the WHOLE train set (the criterion's global
+    normaliser assumes one weight vector): int64 all-reduce of the two pixel counts"""
+    from iswm_amd.utils.loss import calculate_class_weights
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cw_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(11)
+    full = [(torch.rand(2, 16, 16, generator=g) < (0.05 + 0.1 * i)).to(torch.uint8) for i in range(6)]
+    want = calculate_class_weights([(None, x) for x in full])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][1], want)
+
+
+def _ddp_accum_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iswm_amd.parallel import DistributedDataParallelHIP
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 30), torch.nn.Linear(30, 2000), torch.nn.Linear(2000, 3))
+    for p in net[0].parameters():
+        p.requires_grad_(False)                                   # a frozen layer: never reports, its bucket never fires
+    ddp = DistributedDataParallelHIP(net, bucket_mb=0.1)
+    params = list(net.parameters())
+
+    def backward(scale):                                           # stands in for the hand-written backward
+        for i in range(len(params) - 1, -1, -1):
+            p = params[i]
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = p._iswm_grad_view
+                p.grad.zero_()
+            p.grad.add_(scale * float(rank + 1) * (i + 1))
+            ddp._on_ready(p)
+
+    ddp._left = list(ddp._need)
+    with ddp.no_sync():                                            # first micro-batch: local accumulation only
+        backward(1.0)
+    assert not ddp._works
+    ddp._left = list(ddp._need)
+    backward(10.0)                                                 # second micro-batch: the accumulated sum is all-reduced
+    ddp.finish_grad_sync()
+    ok = all(bool((p.grad == 11.0 * 3.0 * (i + 1)).all()) for i, p in enumerate(params) if p.requires_grad)
+    frozen_untouched = all(p.grad is None for p in net[0].parameters())
+    st = ddp.comm_stats()
+    q.put((rank, ok and frozen_untouched, st["bytes_allreduced"], st["allreduces"], st["world_size"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_gradient_accumulation_and_frozen_parameters_gloo_world2():
+    """two backward calls per optimizer step (no_sync around the first) sum correctly across ranks; a frozen layer
+    neither blocks its bucket nor receives a gradient; the communication counters add up"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[4] == 2 and r[3] >= 1 and r[2] > 0
+    assert res[0][2] == res[1][2]
+
+
+def test_fused_optimizer_loads_stock_torch_state():
+    """a checkpoint written by the reference holds torch.optim.AdamW / SGD state (train.py:567-582): the fused classes
+    restore its moments into their arenas and keep their own hyper-parameter keys"""
+    from iswm_amd.optim import FusedAdamW, FusedSGD
+    torch.manual_seed(3)
+    ref_p = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(11))]
+    ref = torch.optim.AdamW(ref_p, weight_decay=1e-2)
+    for p in ref_p:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    sd = ref.state_dict()
+    mine_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    opt = FusedAdamW(mine_p, weight_decay=1e-2)
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["decoupled"] is True and opt._t == 1
+    for p, q in zip(mine_p, ref_p):
+        assert torch.equal(opt.state[p]["exp_avg"], ref.state[q]["exp_avg"])
+        assert torch.equal(opt.state[p]["exp_avg_sq"], ref.state[q]["exp_avg_sq"])
+        assert opt.state[p]["exp_avg"].data_ptr() >= opt._m.data_ptr()          # restored INTO the arena
+    ref2 = torch.optim.SGD(ref_p, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    ref2.step()
+    opt2 = FusedSGD([torch.nn.Parameter(p.detach().clone()) for p in ref_p], momentum=0.9, nesterov=True, weight_decay=1e-4)
+    opt2.load_state_dict(ref2.state_dict())
+    for p, q in zip(opt2.arena.params, ref_p):
+        assert torch.equal(opt2.state[p]["momentum_buffer"], ref2.state[q]["momentum_buffer"])
+    assert opt2.param_groups[0]["nesterov"] is True
+
+
+def test_resume_scoring_of_a_reference_checkpoint():
+    """the reference stores best_score as a dictionary of metrics next to `weighted_score` (train.py:567-582, 799-811)"""
+    from iswm_amd.train import scalar_score
+    assert scalar_score(0.71) == 0.71
+    assert scalar_score({"Foreground IoU": 0.5, "Foreground F1": 0.7}, 0.63) == 0.63
+    assert abs(scalar_score({"Foreground IoU": 0.5, "Foreground F1": 0.7}) - 0.6) < 1e-12
+

@@ -1,0 +1,283 @@
+"""The pre-split ("planes") data path: activations stored as their exact 3-way bf16 split, the convolution kernels that
+consume them (csrc/conv_mfma_pl2.hip, csrc/conv_wgrad_pl.hip) and the memory-bound passes that produce them.
+
+Kernel level vs stock fp32 ATen ops on the CPU (same bounds as tests/test_hip_kernels.py), plus the properties the
+format itself promises: split -> join is the identity bit for bit, and a network evaluated with pre-split activations
+matches the same network on fp32 activations to fp32 rounding."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import RTOL, load, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; the product has no CPU path")
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def to_nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(dev())
+
+
+def to_nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def test_split_join_is_exact_and_handles_slices():
+    from iswm_amd import ops
+    x = rnd(3, 11, 13, 72, seed=1).to(dev())
+    # exact for every value whose residuals stay normal numbers (|x| >= 2^-110); below that the pieces are denormals that
+    # truncation cannot renormalise and the join is off by < 2^-133 in absolute terms (checked separately)
+    x[0, 0, 0, :8] = torch.tensor([0.0, 1e-30, -1e-30, -3e38, 1.0, -1.0, 65504.0, 3.0e38])
+    p = ops.split_planes(x)
+    assert torch.equal(p.f32(), x)                                   # hi + mid + lo == x, bit for bit
+    tiny = torch.full((1, 1, 1, 8), 1e-38, device=dev())
+    assert float((ops.split_planes(tiny).f32() - tiny).abs().max()) < 2.0 ** -133
+    hi = p.t[0].float()
+    assert torch.equal(hi.view(torch.int32) & 0xFFFF, torch.zeros_like(hi, dtype=torch.int32))
+    assert torch.equal(torch.signbit(hi[x != 0]), torch.signbit(x[x != 0]))
+    sl = p[..., 8:40]                                                 # a channel slice of a wider buffer
+    assert sl.shape == (3, 11, 13, 32) and torch.equal(sl.f32(), x[..., 8:40])
+    buf = ops.new_planes(3, 11, 13, 96, dev(), zero=True)
+    ops.split_planes(x[..., :64].contiguous(), out=buf[..., 16:80])
+    full = buf.f32()
+    assert torch.equal(full[..., 16:80], x[..., :64]) and float(full[..., :16].abs().max()) == 0.0
+
+
+PL_CASES = [
+    # cin, cout, k, stride, pad, dil, h, w, n
+    (64, 64, 1, 1, 0, 1, 17, 19, 2),
+    (256, 64, 1, 1, 0, 1, 33, 33, 2),        # 64 columns: the 2 x 4 wave layout
+    (64, 256, 1, 1, 0, 1, 33, 33, 5),
+    (256, 128, 1, 2, 0, 1, 33, 33, 2),       # strided 1x1 (parity-ordered data gradient with empty tiles)
+    (64, 64, 3, 2, 1, 1, 33, 33, 2),
+    (128, 128, 3, 1, 2, 2, 17, 17, 2),
+    (64, 256, 3, 1, 6, 6, 33, 33, 2),        # ASPP rates
+    (64, 256, 3, 1, 18, 18, 17, 17, 2),      # padding-dominated
+    (320, 256, 3, 1, 1, 1, 21, 21, 1),       # decoder: 5 stages per tap, 3 column tiles in the data gradient
+    (256, 48, 1, 1, 0, 1, 21, 21, 2),        # Cout = 48: forward on planes, gradients fall back
+    (1280, 256, 1, 1, 0, 1, 17, 17, 2),
+    (128, 200, 3, 2, 1, 1, 23, 19, 5),
+    (2048, 256, 1, 1, 0, 1, 1, 1, 4),        # 1x1 spatial
+]
+
+
+@pytest.mark.parametrize("case", PL_CASES)
+def test_conv_on_planes_fwd_dgrad_wgrad(case):
+    """iswm_conv2d_fwd_pl2 / _dgrad_pl2 / iswm_conv2d_wgrad_planes through the op wrappers vs F.conv2d and autograd on the
+    CPU; the fused BatchNorm partials are checked through bn_finalize against the batch statistics"""
+    from iswm_amd import ops
+    cin, cout, k, stride, pad, dil, h, w, n = case
+    if not ops.planes_on():
+        pytest.skip("planes are a bf16x6 feature")
+    x = rnd(n, cin, h, w, seed=3).requires_grad_(True)
+    wt = (rnd(cout, cin, k, k, seed=4) * (2.0 / (cin * k * k)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride, pad, dil)
+    up = rnd(*y.shape, seed=5)
+    y.backward(up)
+    xp = ops.split_planes(to_nhwc(x.detach()))
+    wo = wt.detach().permute(0, 2, 3, 1).contiguous().to(dev())
+    g = ops.ConvGeom(xp, cout, k, k, stride, pad, dil)
+    yh, partials, tiles = ops.conv2d_fwd(xp, wo, g, want_stats=True)
+    assert rel_err(to_nchw(yh), y) <= 2e-5
+    cnt = n * g.ho * g.wo
+    if cnt > 1:
+        gamma, beta = torch.ones(cout, device=dev()), torch.zeros(cout, device=dev())
+        rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
+        coef = ops.bn_finalize(partials, tiles[0], cnt, tiles[1], gamma, beta, rm, rv, 0.1)
+        yc = y.detach().permute(1, 0, 2, 3).reshape(cout, -1).double()
+        assert rel_err(coef[2], yc.mean(1).float()) <= 2e-5
+        assert rel_err(1.0 / coef[3] ** 2, (yc.var(1, unbiased=False) + 1e-5).float()) <= 1e-4
+    dyp = ops.split_planes(to_nhwc(up))
+    dx = ops.conv2d_dgrad(dyp, wo, g, (n, h, w, cin))
+    assert rel_err(to_nchw(dx), x.grad) <= 2e-5
+    acc = torch.ones(n, h, w, cin, device=dev())
+    ops.conv2d_dgrad(dyp, wo, g, (n, h, w, cin), dx=acc, accumulate=True)
+    assert rel_err(to_nchw(acc) - 1.0, x.grad) <= 5e-5
+    dw = ops.conv2d_wgrad(xp, dyp, g)
+    assert rel_err(dw.cpu().permute(0, 3, 1, 2), wt.grad) <= 5e-5
+    dw2 = ops.conv2d_wgrad(xp, to_nhwc(up), g)                       # fp32 dy is split on the way in
+    assert torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, True), (6, False)])
+def test_batchnorm_passes_on_planes(relu, res):
+    """bn_apply writing planes (with a planes residual) and bn_backward reading the saved output from its hi plane and
+    writing dy as planes: bit-identical to the fp32 forms of the same kernels"""
+    from iswm_amd import ops
+    n, h, w, c = 3, 9, 11, 72
+    y = rnd(n, h, w, c, seed=7).to(dev())
+    r = rnd(n, h, w, c, seed=8).to(dev())
+    coef = torch.stack([torch.rand(c) + 0.5, torch.randn(c) * 0.1, torch.randn(c) * 0.1, torch.rand(c) + 0.5]).to(dev())
+    o_f = ops.bn_apply(y, coef, relu, r if res else None)
+    o_p = ops.bn_apply(y, coef, relu, ops.split_planes(r) if res else None, planes=True)
+    assert ops.is_planes(o_p) and torch.equal(o_p.f32(), o_f)
+    wide = ops.new_planes(n, h, w, 128, dev())
+    ops.bn_apply(y, coef, relu, r if res else None, out=wide[..., 40:112])
+    assert torch.equal(wide[..., 40:112].f32(), o_f)
+    dout = rnd(n, h, w, c, seed=9).to(dev())
+    gamma = (torch.rand(c) + 0.5).to(dev())
+    dg_f, db_f, dg_p, db_p = (torch.empty(c, device=dev()) for _ in range(4))
+    dy_f, dr_f = ops.bn_backward(dout, o_f if relu else None, y, coef, gamma, relu, True, dg_f, db_f, want_dres=res)
+    dy_p, dr_p = ops.bn_backward(dout, o_p if relu else None, y, coef, gamma, relu, True, dg_p, db_p, want_dres=res,
+                                 dy_planes=True)
+    assert ops.is_planes(dy_p) and torch.equal(dy_p.f32(), dy_f) and torch.equal(dg_f, dg_p) and torch.equal(db_f, db_p)
+    if res:
+        assert torch.equal(dr_f, dr_p)
+
+
+def test_pool_resize_broadcast_on_planes():
+    from iswm_amd import ops
+    x = rnd(2, 17, 19, 64, seed=11).to(dev())
+    y_f, i_f = ops.maxpool_fwd(x)
+    y_p, i_p = ops.maxpool_fwd(x, planes=True)
+    assert torch.equal(y_p.f32(), y_f) and torch.equal(i_f, i_p)
+    assert torch.equal(ops.gap_fwd(ops.split_planes(x)), ops.gap_fwd(x))
+    buf = ops.new_planes(2, 33, 35, 96, dev(), zero=True)
+    ops.bilinear_fwd(x, 33, 35, out=buf[..., 32:96])
+    assert torch.equal(buf[..., 32:96].f32(), ops.bilinear_fwd(x, 33, 35))
+    v = rnd(2, 1, 1, 64, seed=12).to(dev())
+    ops.bcast_fwd(v, buf[..., 0:64])
+    assert torch.equal(buf[..., 0:64].f32(), v.expand(2, 33, 35, 64))
+
+
+def _step(m, x, lab, w):
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    for p in m.parameters():
+        p.grad = None
+    lg = m(x)
+    loss = CrossEntropyLoss(weight=w)(lg, lab)
+    loss.backward()
+    return lg.detach(), loss.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+def test_network_on_planes_matches_network_on_fp32_activations(monkeypatch):
+    """deeplabv3plus_resnet50 forward + weighted CE + backward with pre-split activations vs the SAME kernels' fp32-input
+    forms (planes switched off): logits and loss to 2e-4, gradients to the relative-L2 level two fp32 evaluations of this
+    graph agree to (a flipped near-zero ReLU moves small-batch gradients by O(1/pixels), tests/util.robust_err)"""
+    from iswm_amd import ops
+    from iswm_amd.network import modeling
+    from oracle.synth import ArchCfg, synth_images, synth_labels, synth_state_dict
+    if not ops.planes_on():
+        pytest.skip("planes are a bf16x6 feature")
+    sd = synth_state_dict(ArchCfg("deeplabv3plus", "resnet50", 2, 16))
+    m = modeling.deeplabv3plus_resnet50(num_classes=2, output_stride=16)
+    m.load_state_dict(sd, strict=True)
+    m.classifier.aspp.project[3].p = 0.0
+    m = m.to(dev()).train()
+    x = synth_images(4, 65, 65, seed=21).to(dev())
+    lab = synth_labels(4, 65, 65, seed=21, p_fg=0.2, p_ignore=0.05).to(dev())
+    w = torch.tensor([1.0, 3.0])
+    lg_p, loss_p, g_p = _step(m, x, lab, w)
+    m.load_state_dict(sd, strict=True)                               # same running statistics for the second evaluation
+    monkeypatch.setattr(ops, "_PLANES_ENV", False)
+    lg_f, loss_f, g_f = _step(m, x, lab, w)
+    assert rel_err(lg_p, lg_f) <= 2e-4 and rel_err(loss_p, loss_f) <= 2e-4
+    for k in g_p:
+        a, b = g_p[k].double().flatten(), g_f[k].double().flatten()
+        assert float((a - b).norm() / (b.norm() + 1e-30)) <= 5e-2, k
+
+
+def test_stem_stage_vs_reference_golden():
+    """stem.npz (generated from the reference's ResNet stem: conv 7x7/2 + BN + ReLU + max-pool on [2,3,65,65]) on the
+    GPU: the stage output and the parameter gradients"""
+    from iswm_amd import ops
+    from iswm_amd.network import _hip
+    from iswm_amd.network.backbone import resnet
+    from oracle.synth import synth_images, synth_tensor
+    from tests.test_oracle_golden import upstream
+    from tests.util import check, check_grad
+    fx = load("stem.npz")
+    net = resnet.resnet50(replace_stride_with_dilation=[False, False, True])
+    sd = {"conv1.weight": synth_tensor("backbone.conv1.weight", (64, 3, 7, 7))}
+    for nm, shp in (("weight", (64,)), ("bias", (64,)), ("running_mean", (64,)), ("running_var", (64,))):
+        sd["bn1." + nm] = synth_tensor("backbone.bn1." + nm, shp)
+    net.load_state_dict(sd, strict=False)
+    net = net.to(dev()).train()
+    x = synth_images(2, 65, 65, seed=41).to(dev())
+    xh = ops.nchw_to_nhwc(x)
+    o, ctx = _hip.cba_fwd(net.conv1, net.bn1, True, xh, True, out_fmt="f32")
+    y = net.maxpool.fwd(o, True)
+    check(ops.nhwc_to_nchw(y), fx, "train_out", 1e-4)
+    up = upstream((2, 64, 17, 17), 8).to(dev())
+    dy = net.maxpool.bwd(ops.nchw_to_nhwc(up), None)
+    sink = _hip.GradSink()
+    _hip.cba_bwd(net.conv1, net.bn1, ctx, dy, sink, need_dx=False)
+    check_grad(net.conv1.weight.grad.cpu(), fx, "grad.conv1.weight", 2e-4)
+    check_grad(net.bn1.weight.grad.cpu(), fx, "grad.bn1.weight", 2e-4)
+    check_grad(net.bn1.bias.grad.cpu(), fx, "grad.bn1.bias", 2e-4)
+
+
+def test_frozen_parameters_are_not_touched_by_the_fused_optimizers():
+    """torch.optim skips parameters without a gradient: a frozen backbone keeps its weights bit for bit through steps with
+    weight decay and momentum (the flat-arena kernels only run over the ranges that have gradients)"""
+    from iswm_amd.network import modeling
+    from iswm_amd.optim import FusedAdamW, FusedSGD
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle.synth import synth_images, synth_labels
+    for make in (lambda ps: FusedSGD(ps, momentum=0.9, nesterov=True, weight_decay=1e-2),
+                 lambda ps: FusedAdamW(ps, weight_decay=1e-2)):
+        m = modeling.deeplabv3plus_resnet50(num_classes=2, output_stride=16).to(dev()).train()
+        for p in m.backbone.parameters():
+            p.requires_grad_(False)
+        opt = make(m.parameters())
+        before = {k: v.detach().clone() for k, v in m.backbone.named_parameters()}
+        head0 = m.classifier.classifier[0].weight.detach().clone()
+        x = synth_images(2, 65, 65, seed=5).to(dev())
+        lab = synth_labels(2, 65, 65, seed=5, p_fg=0.2).to(dev())
+        for _ in range(2):
+            opt.zero_grad()
+            CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]))(m(x), lab).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        for k, v in m.backbone.named_parameters():
+            assert torch.equal(v, before[k]), k
+        assert not torch.equal(m.classifier.classifier[0].weight, head0)
+
+
+def test_baseline_config2_per_gpu_workload():
+    """BASELINE.json configs[2] as one GPU sees it: deeplabv3plus_resnet101 os16, 16 x 513 x 513, one training step --
+    finite loss, a bit-identical repeat, and the bf16x6 arithmetic against the exact-fp32 MFMA kernels"""
+    from iswm_amd import _lib
+    from iswm_amd.network import modeling
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    lib = _lib.load()
+    torch.manual_seed(1)
+    m = modeling.deeplabv3plus_resnet101(num_classes=2, output_stride=16).to(dev()).train()
+    m.classifier.aspp.project[3].p = 0.0
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(16, 3, 513, 513, generator=g).to(dev())
+    lab = (torch.rand(16, 513, 513, generator=g) < 0.1).long().to(dev())
+    crit = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]))
+
+    def run():
+        m.load_state_dict(sd)
+        for p in m.parameters():
+            p.grad = None
+        loss = crit(m(x), lab)
+        loss.backward()
+        return loss.detach().clone(), m.backbone.conv1.weight.grad.detach().clone(), m.classifier.classifier[6].weight.grad.detach().clone()
+
+    l1, g1, h1 = run()
+    l2, g2, h2 = run()
+    assert bool(torch.isfinite(l1)) and torch.equal(l1, l2) and torch.equal(g1, g2) and torch.equal(h1, h2)
+    old = lib.iswm_get_conv_math()
+    try:
+        lib.iswm_set_conv_math(0)
+        l3, _, _ = run()
+    finally:
+        lib.iswm_set_conv_math(old)
+    assert abs(float(l1) - float(l3)) <= 1e-4 * abs(float(l3))

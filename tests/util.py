@@ -57,8 +57,10 @@ def robust_err(actual, expected, q=0.995):
     that sit within rounding of zero may get opposite signs, and with the few hundred pixels per
     channel of the golden cases ONE flipped ReLU shifts that channel's BatchNorm gradient sums, and
     with them every gradient downstream, by O(1/pixels) ~ 2e-3.  These checks therefore bound the
-    relative L2 error (5e-2: catches any wrong formula, layout or scale); the element-wise 1e-3 bound
-    is enforced with identical sign patterns (same-mask tests)."""
+    relative L2 error AND two quantiles of the element-wise error (check_grad_robust / check_robust: q90 <= 2e-3,
+    q99.5 <= 1e-2, L2 <= 1e-2 -- measured over all 278 comparisons of the suite: q90 <= 1.4e-3, q99.5 <= 5.8e-3,
+    L2 <= 3.6e-3, medians ~1e-4): a wrong formula, layout or scale on any tensor, however small, moves the MEDIAN
+    error to O(1).  The element-wise 1e-3 bound itself is enforced with identical sign patterns (same-mask tests)."""
     a = actual.detach().cpu().double().numpy() if torch.is_tensor(actual) else np.asarray(actual, dtype=np.float64)
     e = expected.detach().cpu().double().numpy() if torch.is_tensor(expected) else np.asarray(expected, dtype=np.float64)
     assert a.shape == e.shape, (a.shape, e.shape)
@@ -67,7 +69,18 @@ def robust_err(actual, expected, q=0.995):
     return float(np.quantile(d, q) / scale), float(np.linalg.norm(d) / (np.linalg.norm(e.ravel()) or 1.0))
 
 
-def check_grad_robust(p_grad, fx, key, tol=None, l2_tol=5e-2):
+def _report(name, a, e, qerr, l2):
+    if os.environ.get("ISWM_TEST_REPORT"):
+        q50 = robust_err(a, e, 0.5)[0]
+        q90 = robust_err(a, e, 0.9)[0]
+        with open(os.environ["ISWM_TEST_REPORT"], "a") as f:
+            f.write("%-40s q50 %.2e q90 %.2e q99.5 %.2e L2 %.2e max %.2e\n" % (name, q50, q90, qerr, l2, rel_err(a, e)))
+
+
+Q90_TOL, Q995_TOL, L2_TOL = 2e-3, 1e-2, 1e-2
+
+
+def check_grad_robust(p_grad, fx, key, tol=Q995_TOL, l2_tol=L2_TOL):
     if key + "__first8" in fx.files:
         exp, g = fx[key + "__first8"], p_grad[:8]
     else:
@@ -75,13 +88,19 @@ def check_grad_robust(p_grad, fx, key, tol=None, l2_tol=5e-2):
         if exp.shape != tuple(g.shape):
             g = g[:8]
     qerr, l2 = robust_err(g, exp)
-    assert (tol is None or qerr <= tol) and l2 <= l2_tol, "%s: q99.5 err %.3e, L2 err %.3e" % (key, qerr, l2)
+    q90 = robust_err(g, exp, 0.9)[0]
+    _report(key, g, exp, qerr, l2)
+    assert (tol is None or qerr <= tol) and q90 <= Q90_TOL and l2 <= l2_tol, \
+        "%s: q90 err %.3e, q99.5 err %.3e, L2 err %.3e" % (key, q90, qerr, l2)
 
 
-def check_robust(actual, fx, name, tol=None, l2_tol=5e-2):
+def check_robust(actual, fx, name, tol=Q995_TOL, l2_tol=L2_TOL):
     step = int(fx[name + "__cstep"]) if (name + "__cstep") in fx.files else 1
     a = actual.detach().cpu()
     if step > 1:
         a = a[:, ::step]
     qerr, l2 = robust_err(a, fx[name])
-    assert (tol is None or qerr <= tol) and l2 <= l2_tol, "%s: q99.5 err %.3e, L2 err %.3e" % (name, qerr, l2)
+    q90 = robust_err(a, fx[name], 0.9)[0]
+    _report(name, a, fx[name], qerr, l2)
+    assert (tol is None or qerr <= tol) and q90 <= Q90_TOL and l2 <= l2_tol, \
+        "%s: q90 err %.3e, q99.5 err %.3e, L2 err %.3e" % (name, q90, qerr, l2)
