@@ -35,16 +35,38 @@ X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 # HBM bytes per launch of each kernel, averaged over the launches of one training step of THIS workload, from
 # two rocprofv3 PMC passes over tools/pmc_step.py (FETCH_SIZE, WRITE_SIZE; FETCH_SIZE doubled per the gfx950
-# wide-read correction of the MI355X guide), aggregated by tools/pmc_aggregate.py into profiles/.
+# wide-read correction of the MI355X guide), aggregated by tools/pmc_aggregate.py into profiles/.  The table records a
+# hash of the kernel sources it was measured on: `traffic` is reported only when that hash matches the sources of the
+# build being timed; otherwise it is null and the stale figure is returned under its own name.
+PMC_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc", "step_traffic.json")
+
+
+def csrc_hash():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "iswm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc", "step_traffic.json")
+    """(bytes per launch | None, {"bytes", "csrc_sha16"} of a stale table | None)"""
     try:
-        with open(path) as f:
+        with open(PMC_TABLE) as f:
             table = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
     ent = table.get(kernel.replace("+reduce", ""))
-    return round(ent["hbm_bytes_per_launch"]) if ent else None
+    if not ent:
+        return None, None
+    val = round(ent["hbm_bytes_per_launch"])
+    sha = table.get("_csrc_sha16")
+    if sha == csrc_hash():
+        return val, None
+    return None, {"bytes": val, "csrc_sha16": sha}
 
 
 def parse():
@@ -183,8 +205,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch one rank per GPU with torch.distributed.run)" %
+                         (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # rehearsal knobs (single-GPU box): ISWM_DIST_BACKEND=gloo runs the N > 1 path with every rank on GPU
@@ -200,6 +223,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from iswm_amd import _lib, ops
     from iswm_amd.network import modeling
@@ -280,11 +304,30 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.KPROF = None
+    comm = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        # what the first real multi-GPU run should tell about itself: volume, launches, the time the compute stream stood
+        # still waiting for the last buckets (exposed = not hidden behind backward), and that every rank was there
+        st = net.comm_stats()
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        nsteps = max(1, st["steps"])
+        comm = {"backend": st["backend"], "ranks_seen": int(seen.item()), "buckets": st["buckets"],
+                "allreduces_per_step": round(st["allreduces"] / nsteps, 2),
+                "bytes_allreduced_per_step": int(st["bytes_allreduced"] / nsteps),
+                "exposed_wait_ms_per_step": round(st["exposed_wait_ms"] / nsteps, 3),
+                "note": "rank 0's view; exposed_wait = compute stream stalled in finish_grad_sync (includes warm-up steps)"}
     final_loss = float(loss.detach())
+    # host cost of enqueuing ONE step into an idle queue (the timed loop's enqueue time is back-pressure: the host runs
+    # into the launch queue limit and then advances at the GPU's pace)
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    step()
+    host_idle_ms = (time.perf_counter() - th) * 1e3
+    torch.cuda.synchronize()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -318,15 +361,18 @@ def main():
                 "parallelism": "dp%d" % world,
             },
             "final_loss": round(final_loss, 6),
-            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
+            "host_enqueue_ms_idle": round(host_idle_ms, 3),
+            "host_enqueue_ms_backpressured": round(t_enqueued / args.steps * 1e3, 3),
         }
+        if comm is not None:
+            out["comm"] = comm
         if kprof is not None:
             summ = kprof.summary()
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             name, d = dom
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            is_x6 = math_name == "bf16x6" and ("x6" in name or ", true, 3>" in name)
-            is_b16 = math_name == "bf16" and ("x6" in name or ", true, 1>" in name)
+            is_x6 = math_name == "bf16x6" and ("x6" in name or ", true, 3>" in name or name.startswith(("k_conv_pl", "k_wgrad_pl")))
+            is_b16 = math_name == "bf16" and ("x6" in name or ", true, 1>" in name or name.startswith(("k_conv_pl", "k_wgrad_pl")))
             peak = BF16_MFMA_PEAK_TFLOPS if is_b16 else (X6_PEAK_TFLOPS if is_x6 else FP32_MFMA_PEAK_TFLOPS)
             out["roofline"] = {
                 "kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
@@ -335,10 +381,13 @@ def main():
                                "bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 MAC (bf16x6)" if is_x6
                                else "fp32 MFMA dense peak"),
                 "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(name),
+                "traffic": pmc_traffic(name)[0],
                 "launches": d["launches"], "avg_us": round(d["ms"] * 1e3 / d["launches"], 2),
                 "flops_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
             }
+            stale = pmc_traffic(name)[1]
+            if stale is not None:
+                out["roofline"]["traffic_profiled_build"] = stale      # measured on other kernel sources: not `traffic`
             if warm_summary is not None:
                 out["roofline"]["by_kernel_warmup_step"] = {
                     k: {"ms_per_step": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),

@@ -31,6 +31,14 @@ for k in sorted(set(fetch) | set(write)):
               "write_size_bytes_per_launch": wb / n,
               # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (MI355X guide, HBM)
               "hbm_bytes_per_launch": (2.0 * fb + wb) / n}
+import hashlib, os
+h = hashlib.sha256()
+d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "iswm_amd", "csrc")
+for f in sorted(os.listdir(d)):
+    if f.endswith((".hip", ".h")):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+out["_csrc_sha16"] = h.hexdigest()[:16]          # bench.py reports `traffic` only for a build of these sources
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_2_steps"])[:12]:
+for k, v in sorted(((k, v) for k, v in out.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_2_steps"])[:12]:
     print("%-44s %5d launches  %9.1f MB/launch" % (k, v["launches_2_steps"], v["hbm_bytes_per_launch"] / 1e6))
