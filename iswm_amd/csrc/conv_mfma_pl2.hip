@@ -185,7 +185,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
     struct AFrag {
         uint4 v[NP];
     };
-    auto compute = [&](int st, const BFrag& b) __attribute__((always_inline)) {
+    // Multiply stage `st`; when `more`, the loads of the FOLLOWING stage (weight fragments into bn, activation DMA into stage
+    // buffer st ^ 1) are issued one or two at a time BETWEEN the row blocks.  Issued in one burst at the top of the stage
+    // they serialise with the multiply: with one workgroup per CU the vector-memory path takes ~34 cycles per 1-KB
+    // instruction (30 B/clk/CU, tools/ta_bw.hip) and a wave sits in the issue queue instead of feeding the matrix pipe.
+    auto compute = [&](int st, const BFrag& b, bool more, BFrag& bn, int k32n) __attribute__((always_inline)) {
         // fragments of row block i+1 are read while block i is multiplied; the scheduling fences keep hipcc from
         // hoisting all 2 * RBW * NP fragment reads of a stage to its top (216 VGPRs for RBW = 9)
         auto aload = [&](AFrag& f, int idx) __attribute__((always_inline)) {          // idx = half * RBW + rb
@@ -208,18 +212,41 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             c = mfma16(b.v[half][0], f.v[0], c);
             acc[rb] = c;
         };
+        constexpr int NB_SLOTS = 2 * NP, NA_SLOTS = NRG * NP, NSLOTS = NB_SLOTS + NA_SLOTS;
+        constexpr int PER = (NSLOTS + 2 * RBW - 1) / (2 * RBW);          // load slots per row block
+        const uint4* wn_ = wpk + (size_t)k32n * (64 * NP);
+        auto slot = [&](int sidx) __attribute__((always_inline)) {
+            if (sidx < NB_SLOTS) {
+                bn.v[sidx / NP][sidx % NP] = wn_[sidx * 64];
+            } else if (sidx < NSLOTS) {
+                const int i = (sidx - NB_SLOTS) / NP, pp = (sidx - NB_SLOTS) % NP;
+                if (wave + 8 * i < RG) glds16b(aptr[i] + pp * pst[i], lds_base + (st ^ 1) * STAGE + pp * PLANE + (wave + 8 * i) * 1024);
+            }
+        };
         AFrag f0, f1;
         aload(f0, 0);
 #pragma unroll
         for (int idx = 0; idx < 2 * RBW; idx += 2) {
             if (idx + 1 < 2 * RBW) aload(f1, idx + 1);
             mul(f0, idx);
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < PER; ++q) slot(idx * PER + q);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (idx + 1 < 2 * RBW) {
                 if (idx + 2 < 2 * RBW) aload(f0, idx + 2);
                 mul(f1, idx + 1);
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) slot((idx + 1) * PER + q);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NRG; ++i) aptr[i] += astep[i];
         }
     };
 
@@ -374,11 +401,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             bool more = next_in_tile();
             const bool last = !more;                      // the stage in hand is the last of its tile
             if (last) more = next_tile_stage();
-            if (more) {
-                bload(bn, tap * (GC >> 5) + 2 * cc);
-                issueA(st ^ 1);
-            }
-            compute(st, bc);
+            compute(st, bc, more, bn, more ? tap * (GC >> 5) + 2 * cc : 0);
             if (last) {
                 epilogue(c_tile, c_m0, c_n0, false);
                 c_tile = i_tile; c_m0 = i_m0; c_n0 = i_n0;
