@@ -401,7 +401,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             bool more = next_in_tile();
             const bool last = !more;                      // the stage in hand is the last of its tile
             if (last) more = next_tile_stage();
-            compute(st, bc, more, bn, more ? tap * (GC >> 5) + 2 * cc : 0);
+            if (a.nsplit) {                    // tuning switch ISWM_PL2_BURST=1: all loads of the next stage at the top of this one
+                if (more) {
+                    bload(bn, tap * (GC >> 5) + 2 * cc);
+                    issueA(st ^ 1);
+                }
+                compute(st, bc, false, bn, 0);
+            } else {
+                compute(st, bc, more, bn, more ? tap * (GC >> 5) + 2 * cc : 0);
+            }
             if (last) {
                 epilogue(c_tile, c_m0, c_n0, false);
                 c_tile = i_tile; c_m0 = i_m0; c_n0 = i_n0;
@@ -449,7 +457,9 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
         if (const char* g = getenv("ISWM_PL2_GRID")) ncu = atoi(g) > 0 ? atoi(g) : ncu;
     }
     a.psplit = parity ? 0 : 1;
-    a.nsplit = rbw;
+    static int burst = -1;
+    if (burst < 0) burst = (getenv("ISWM_PL2_BURST") && atoi(getenv("ISWM_PL2_BURST"))) ? 1 : 0;
+    a.nsplit = burst;
     const int nc = dgrad ? a.Cin : a.Cout;
     const bool narrow = nc <= 64;
     a.MT = (a.M + rbw * 16 - 1) / (rbw * 16);

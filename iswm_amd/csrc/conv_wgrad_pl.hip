@@ -51,10 +51,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pl(const WgArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    // split-major order over a flat grid, dealt to the XCDs in contiguous runs: the workgroups of one pixel split (all tiles
+    // over the same dy / x pixel range) share an L2 -- each operand byte then leaves HBM / Infinity Cache about once instead
+    // of once per tile row / column
+    const int tiles = a.MT * a.NT;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = L / a.NT, nt = L - mt * a.NT;
+    const int split = L / tiles, tile = L - split * tiles;
+    const int mt = tile / a.NT, nt = tile - mt * a.NT;
     const int m0 = mt * 128, n0 = nt * 128;
-    const int split = blockIdx.y;
     const int p_begin = split * a.psplit;
     const int p_end = min(a.P, p_begin + a.psplit);
     const int nK = (p_end - p_begin + 31) >> 5;
@@ -286,7 +290,7 @@ void plan_wgrad_pl(int Cout, int Ktot, int64_t P, int* nsplit, int* psplit) {
 }
 
 void launch_wgrad_pl(const WgArgs& a, int planes, hipStream_t s) {
-    dim3 grid(a.MT * a.NT, a.nsplit), blk(512);
+    dim3 grid(a.MT * a.NT * a.nsplit), blk(512);
     if (planes == 1) hipLaunchKernelGGL(k_wgrad_pl<1>, grid, blk, 0, s, a);
     else hipLaunchKernelGGL(k_wgrad_pl<3>, grid, blk, 0, s, a);
 }
