@@ -177,16 +177,13 @@ __global__ __launch_bounds__(256) void k_bn_apply8(const float* __restrict__ y, 
     const int c = rt.c4 * 8;
     const float4 sc0 = ld4(scale + c), sc1 = ld4(scale + c + 4), sh0 = ld4(shift + c), sh1 = ld4(shift + c + 4);
     const float4 mu0 = ld4(mean + c), mu1 = ld4(mean + c + 4);
-    for (int64_t r = rt.row0; r < M; r += rt.rstep) {
-        const float4 v0 = ld4(y + r * ldy + c), v1 = ld4(y + r * ldy + c + 4);
+    auto one = [&](int64_t r, const float4 v0, const float4 v1, const float4 q0, const float4 q1) {
         float4 o0, o1;
         o0.x = (v0.x - mu0.x) * sc0.x + sh0.x; o0.y = (v0.y - mu0.y) * sc0.y + sh0.y;
         o0.z = (v0.z - mu0.z) * sc0.z + sh0.z; o0.w = (v0.w - mu0.w) * sc0.w + sh0.w;
         o1.x = (v1.x - mu1.x) * sc1.x + sh1.x; o1.y = (v1.y - mu1.y) * sc1.y + sh1.y;
         o1.z = (v1.z - mu1.z) * sc1.z + sh1.z; o1.w = (v1.w - mu1.w) * sc1.w + sh1.w;
         if (RES) {
-            float4 q0, q1;
-            ld8x(res, r * ldr + c, rps, q0, q1);
             o0.x += q0.x; o0.y += q0.y; o0.z += q0.z; o0.w += q0.w;
             o1.x += q1.x; o1.y += q1.y; o1.z += q1.z; o1.w += q1.w;
         }
@@ -199,6 +196,27 @@ __global__ __launch_bounds__(256) void k_bn_apply8(const float* __restrict__ y, 
             o1.x = fminf(o1.x, 6.f); o1.y = fminf(o1.y, 6.f); o1.z = fminf(o1.z, 6.f); o1.w = fminf(o1.w, 6.f);
         }
         st8x(out, r * ldo + c, ops, o0, o1);
+    };
+    // two rows per iteration: twice the loads in flight per thread (the one-row loop ran at 3.8 TB/s)
+    int64_t r = rt.row0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; r + rt.rstep < M; r += 2 * rt.rstep) {
+        const int64_t r2 = r + rt.rstep;
+        const float4 a0 = ld4(y + r * ldy + c), a1 = ld4(y + r * ldy + c + 4);
+        const float4 b0 = ld4(y + r2 * ldy + c), b1 = ld4(y + r2 * ldy + c + 4);
+        float4 qa0 = z4, qa1 = z4, qb0 = z4, qb1 = z4;
+        if (RES) {
+            ld8x(res, r * ldr + c, rps, qa0, qa1);
+            ld8x(res, r2 * ldr + c, rps, qb0, qb1);
+        }
+        one(r, a0, a1, qa0, qa1);
+        one(r2, b0, b1, qb0, qb1);
+    }
+    if (r < M) {
+        const float4 a0 = ld4(y + r * ldy + c), a1 = ld4(y + r * ldy + c + 4);
+        float4 qa0 = z4, qa1 = z4;
+        if (RES) ld8x(res, r * ldr + c, rps, qa0, qa1);
+        one(r, a0, a1, qa0, qa1);
     }
 }
 

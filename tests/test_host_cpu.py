@@ -36,9 +36,17 @@ def test_stat_tile_queries_are_pure_host_functions():
     rows = lib.iswm_conv2d_stat_tile_rows(ctypes.byref(d))
     assert rows in (64, 128) and lib.iswm_conv2d_stat_tiles(ctypes.byref(d)) == (16 * 33 * 33 + rows - 1) // rows
     assert lib.iswm_conv2d_wgrad_workspace(ctypes.byref(d)) % (256 * 9 * 2048 * 4) == 0
+    # planes kernels: tile height picked so that tiles ~ k x 256 CUs (33x33x16 -> 144 rows x 128 columns: 242 tiles)
+    d1 = _lib.ConvDesc(16, 33, 33, 1024, 33, 33, 256, 1, 1, 1, 0, 1, 1024, 256)
+    assert lib.iswm_conv2d_pl2_tile_rows(ctypes.byref(d1), 0) == 144
+    assert lib.iswm_conv2d_pl2_weight_bytes(ctypes.byref(d1), 0) == 16 * (1024 // 32) * 3 * 64 * 16      # [256/16][K/32][3][64] x 16 B
+    d48 = _lib.ConvDesc(16, 129, 129, 256, 129, 129, 48, 1, 1, 1, 0, 1, 256, 48)
+    assert lib.iswm_conv2d_pl2_weight_bytes(ctypes.byref(d48), 1) == 0                                     # dgrad gathers 48 channels: not a multiple of 64
+    assert lib.iswm_conv2d_wgrad_planes_ok(ctypes.byref(d48)) == 1 and lib.iswm_conv2d_wgrad_planes_workspace(ctypes.byref(d48)) % (48 * 256 * 4) == 0
     assert lib.iswm_colstat_tiles(1) == 1 and lib.iswm_colstat_tiles(10 ** 7) == 1024
     assert lib.iswm_colstat_tile_rows(578) == 31 and lib.iswm_colstat_tile_rows(1) == 1
-    assert lib.iswm_loss_blocks(513 * 513 * 16) == 1024
+    assert lib.iswm_loss_blocks(513 * 513 * 16) == (513 * 513 * 16 + 1023) // 1024      # 4 pixels per thread, 256 threads
+    assert lib.iswm_loss_blocks(10 ** 9) == 8192 and lib.iswm_loss_blocks(1) == 1
 
 
 @pytest.mark.parametrize("ctor,backbone,nkeys", [("deeplabv3plus_resnet50", "resnet50", 374),
