@@ -147,6 +147,9 @@ int iswm_conv2d_fwd_planes(const iswm_conv_desc* d, const void* xp, int64_t plan
                            const float* bias, float* y, float* stat_partials, iswm_stream_t stream);
 int iswm_conv2d_dgrad_planes(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
                              float* dx, int accumulate, iswm_stream_t stream);
+/* diagnostics: per-stage shader-clock stamps of workgroup 0 of the planes conv kernels into a device buffer of >= 512 uint64
+ * (NULL = off, the default; tools/pl2_timeline.py) */
+int iswm_set_debug_buffer(void* buf);
 /* second-generation planes kernels: (16*rbw) x 128 tiles, weights packed for the 16x16x32 MFMA (own packing) */
 size_t iswm_conv2d_pl2_weight_bytes(const iswm_conv_desc* d, int kind);
 int iswm_conv2d_pl2_pack_weights(const iswm_conv_desc* d, int kind, const float* w, void* packed, iswm_stream_t stream);

@@ -22,6 +22,7 @@ struct ConvArgs {
     int psplit;  // wgrad: pixels per split (multiple of 32)
     int accumulate;  // dgrad: dx += result instead of dx = result
     long long xps;   // plane kernels (conv_mfma_pl.hip): byte stride between the bf16 planes of the gathered operand
+    unsigned long long* dbg;   // diagnostic builds only (iswm_set_debug_buffer): per-stage s_memtime stamps of workgroup 0, wave 0
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

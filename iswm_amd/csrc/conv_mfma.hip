@@ -1130,6 +1130,14 @@ extern "C" int iswm_conv2d_dgrad_planes(const iswm_conv_desc* d, const void* dyp
     return check_launch("conv_dgrad_planes");
 }
 
+namespace iswm { extern unsigned long long* g_conv_dbg; }
+/* diagnostics: a device buffer of >= 512 uint64 that workgroup 0 of the planes conv kernels fills with per-stage shader-clock
+ * stamps (tools/pl2_timeline.py); NULL (the default) switches the stamps off */
+extern "C" int iswm_set_debug_buffer(void* buf) {
+    iswm::g_conv_dbg = reinterpret_cast<unsigned long long*>(buf);
+    return 0;
+}
+
 /* second-generation planes kernels (conv_mfma_pl2.hip): kind 0 forward, 1 data gradient */
 extern "C" size_t iswm_conv2d_pl2_weight_bytes(const iswm_conv_desc* d, int kind) {
     if (!d || conv_math() < 1 || (kind != 0 && kind != 1)) return 0;

@@ -42,6 +42,8 @@ __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
 
 constexpr int PL2_RBWMAX = 10;     // tile height up to 160 rows
 
+unsigned long long* g_conv_dbg = nullptr;        // iswm_set_debug_buffer
+
 // a.x = plane 0 of the gathered operand (bf16), a.ldx = its pixel pitch in bf16 elements, a.xps = plane stride (bytes)
 // a.w = weights packed by k_pack_weights_pl2;  a.MT, a.NT tile counts;  a.psplit != 0: row-major rows for strided dgrad.
 // Tile = (16 * RBW * WM) rows x (128 / WM) columns; wave (wm, wn) owns rows [wm*16*RBW, +16*RBW) and columns 16*wn..+15.
@@ -213,6 +215,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             acc[rb] = c;
         };
         constexpr int NB_SLOTS = 2 * NP, NA_SLOTS = NRG * NP, NSLOTS = NB_SLOTS + NA_SLOTS;
+        // spread evenly over the row blocks (front-loading them -- two per block over the first half of the stage -- measured
+        // 8-12 % slower: the issue burst is what hurts)
         constexpr int PER = (NSLOTS + 2 * RBW - 1) / (2 * RBW);          // load slots per row block
         const uint4* wn_ = wpk + (size_t)k32n * (64 * NP);
         auto slot = [&](int sidx) __attribute__((always_inline)) {
@@ -394,10 +398,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         int st = 0;
         // one step per stage: publish stage `st`, start the loads of the following stage (possibly of the next tile),
         // multiply stage `st`, and run the epilogue when it was the last stage of its tile
+        int dbg_n = 0;
+        const bool dbg = a.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
+        auto stamp = [&](int k) __attribute__((always_inline)) {
+            if (dbg && dbg_n < 40 && lane == 0) a.dbg[(wave ? 256 : 0) + dbg_n * 6 + k] = __builtin_amdgcn_s_memtime();
+        };
         while (have) {
+            stamp(0);
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's DMA pieces and weight fragments landed
+            stamp(1);
             __builtin_amdgcn_s_barrier();                // ... everyone's did; the other stage buffer is free
             asm volatile("" ::: "memory");
+            stamp(2);
             bool more = next_in_tile();
             const bool last = !more;                      // the stage in hand is the last of its tile
             if (last) more = next_tile_stage();
@@ -408,7 +420,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
                 }
                 compute(st, bc, false, bn, 0);
             } else {
+                stamp(3);
                 compute(st, bc, more, bn, more ? tap * (GC >> 5) + 2 * cc : 0);
+                stamp(4);
             }
             if (last) {
                 epilogue(c_tile, c_m0, c_n0, false);
@@ -416,6 +430,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             }
             st ^= 1;
             bc = bn;
+            stamp(5);
+            ++dbg_n;
             have = more;
         }
     }
@@ -457,6 +473,7 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
         if (const char* g = getenv("ISWM_PL2_GRID")) ncu = atoi(g) > 0 ? atoi(g) : ncu;
     }
     a.psplit = parity ? 0 : 1;
+    a.dbg = g_conv_dbg;
     static int burst = -1;
     if (burst < 0) burst = (getenv("ISWM_PL2_BURST") && atoi(getenv("ISWM_PL2_BURST"))) ? 1 : 0;
     a.nsplit = burst;
