@@ -17,6 +17,8 @@
 
 namespace iswm {
 
+extern unsigned long long* g_conv_dbg;
+
 static __device__ __attribute__((aligned(256))) unsigned short g_zero_row_wg[128];   // 256 B of zeros
 
 typedef __attribute__((address_space(3))) void* lds_vptr3;
@@ -36,6 +38,10 @@ struct WgArgs {
     int P, Ktot, MT, NT, nsplit, psplit;
     int abl;                    // timing ablations (ISWM_WG_ABL): 1 no DMA, 2 no multiply
     int always;                 // 1: every gathered pixel is in bounds (1x1 stride-1 pad-0): no per-step culling vote
+    unsigned long long* dbg;    // iswm_set_debug_buffer: per-step shader-clock stamps of workgroup 0 (tools/wgrad_timeline.py)
+    int burst;                  // 1: issue a step's DMA as one burst after the barrier instead of between the multiplies
+    int vote;                   // 1: skip 32-pixel steps whose gathered pixels are ALL padding (workgroup-wide vote, one more
+                                // barrier per step: only worth it when the filter reaches far -- ASPP rates)
 };
 
 template <int NP>
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pl(const WgArgs a) {
             const bool v = pin && bok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
             bsrc = v ? bbase + (size_t)((pn * a.H + ih) * a.W + iw) * a.ldx * 2 : zrow;
             bpst = v ? a.xps : 0;
+            if (!a.vote) return true;
             if (__syncthreads_or(v ? 1 : 0)) return true;
         }
     };
@@ -257,10 +264,270 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pl(const WgArgs a) {
     }
 }
 
+
+// ---- 128 x 256 tile ("wide"): the same DMA / transposing-read machinery on a tile twice as wide along the (tap, ci) axis.
+// Per 32-pixel step a CU now multiplies 128 x 256 x 32 (3 072 matrix cycles per SIMD instead of 1 536) behind ONE barrier,
+// and fetches 72 KB for it (23 B/clk at full matrix rate instead of 31; a single workgroup per CU is fed ~30 B/clk,
+// profiles/r02_ta_bw.txt).  Eight waves as 2 x 4, each a 64 x 64 block over the whole step: no k-half split, so no LDS
+// combine at the end.  Two stage buffers of [A | B0 | B1] images (144 KB).
+template <int NP>
+__global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
+    constexpr int PLANE = 32 * 256;            // bytes of one plane of one 128-channel image of one stage
+    constexpr int IMG = NP * PLANE;
+    constexpr int STAGE = 3 * IMG;             // A image, then the two B images
+    constexpr int NST = 2;
+    constexpr int SMEM = NST * STAGE < 65536 ? 65536 : NST * STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vptr3)smem;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles = a.MT * a.NT;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = L / tiles, tile = L - split * tiles;
+    const int mt = tile / a.NT, nt = tile - mt * a.NT;
+    const int m0 = mt * 128, n0 = nt * 256;
+    const int p_begin = split * a.psplit;
+    const int p_end = min(a.P, p_begin + a.psplit);
+    const int nK = (p_end - p_begin + 31) >> 5;
+
+    const int kr = 4 * wave + (lane >> 4);
+    const int gsrc = (lane & 15) ^ (4 * ((lane >> 4) & 3));
+    const unsigned char* zrow = reinterpret_cast<const unsigned char*>(g_zero_row_wg) + (lane & 15) * 16;
+    const int ach = m0 + 8 * gsrc;
+    const bool aok = ach < a.Cout;
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(a.dy) + (size_t)ach * 2;
+    // the two B images: columns n0 + 8 * gsrc and n0 + 128 + 8 * gsrc of the (tap, ci) axis
+    bool bok[2];
+    int dh[2], dw[2];
+    const unsigned char* bbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int bcol = n0 + 128 * i + 8 * gsrc;
+        bok[i] = bcol < a.Ktot;
+        const int tap = bok[i] ? bcol / a.Cin : 0, bch = bok[i] ? bcol - tap * a.Cin : 0;
+        const int tkh = tap / a.KW, tkw = tap - tkh * a.KW;
+        dh[i] = tkh * a.dil - a.pad;
+        dw[i] = tkw * a.dil - a.pad;
+        bbase[i] = reinterpret_cast<const unsigned char*>(a.x) + (size_t)bch * 2;
+    }
+    const int HoWo = a.Ho * a.Wo;
+
+    const unsigned char* asrc = zrow;
+    const unsigned char* bsrc[2] = {zrow, zrow};
+    long long apst = 0, bpst[2] = {0, 0};
+    int kc = -1;
+    int pn, poh, pow_;
+    {
+        const int p = p_begin + kr;
+        pn = p / HoWo;
+        const int rem = p - pn * HoWo;
+        poh = rem / a.Wo;
+        pow_ = rem - poh * a.Wo;
+    }
+    const int d_oh = 32 / a.Wo, d_ow = 32 - d_oh * a.Wo;
+    const bool fast_adv = d_oh + 1 <= a.Ho;
+    auto next = [&]() __attribute__((always_inline)) -> bool {
+        for (;;) {
+            if (++kc >= nK) return false;
+            const int p = p_begin + kc * 32 + kr;
+            const bool pin = p < p_end;
+            asrc = (pin && aok) ? abase + (size_t)p * a.ldy * 2 : zrow;
+            apst = (pin && aok) ? a.dyps : 0;
+            if (a.always) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool v = pin && bok[i];
+                    bsrc[i] = v ? bbase[i] + (size_t)p * a.ldx * 2 : zrow;
+                    bpst[i] = v ? a.xps : 0;
+                }
+                return true;
+            }
+            if (kc > 0) {
+                if (fast_adv) {
+                    int ow = pow_ + d_ow;
+                    const int c1 = ow >= a.Wo ? 1 : 0;
+                    pow_ = ow - (c1 ? a.Wo : 0);
+                    int oh = poh + d_oh + c1;
+                    const int c2 = oh >= a.Ho ? 1 : 0;
+                    poh = oh - (c2 ? a.Ho : 0);
+                    pn += c2;
+                } else {
+                    pn = p / HoWo;
+                    const int rem = p - pn * HoWo;
+                    poh = rem / a.Wo;
+                    pow_ = rem - poh * a.Wo;
+                }
+            }
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ih = poh * a.stride + dh[i], iw = pow_ * a.stride + dw[i];
+                const bool v = pin && bok[i] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                bsrc[i] = v ? bbase[i] + (size_t)((pn * a.H + ih) * a.W + iw) * a.ldx * 2 : zrow;
+                bpst[i] = v ? a.xps : 0;
+                any = any || v;
+            }
+            if (!a.vote) return true;
+            if (__syncthreads_or(any ? 1 : 0)) return true;
+        }
+    };
+    // DMA instruction i of a step: image i / NP (A, B0, B1), plane i % NP
+    auto dma = [&](int i, int st) __attribute__((always_inline)) {
+        const int img = i / NP, pl = i - img * NP;
+        const unsigned dst = lds_base + st * STAGE + img * IMG + pl * PLANE + wave * 1024;
+        if (img == 0) glds16w(asrc + pl * apst, dst);
+        else glds16w(bsrc[img - 1] + pl * bpst[img - 1], dst);
+    };
+    auto issue = [&](int st) __attribute__((always_inline)) {
+        if (a.abl & 1) return;
+#pragma unroll
+        for (int i = 0; i < 3 * NP; ++i) dma(i, st);
+    };
+
+    const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+    const int th = tg >> 1, tc = (tg & 1) * 16 + tp * 4;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    auto tr_frag = [&](const unsigned char* plane, int ks, int col0) __attribute__((always_inline)) -> uint4 {
+        const unsigned char* p = plane + (ks * 16 + th * 8 + tq) * 256 + (((col0 + tc) * 2) ^ (tq * 64));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 256));
+        uint2 a2 = __builtin_bit_cast(uint2, lo), b2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(a2.x, a2.y, b2.x, b2.y);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // One step = 8 blocks of 6 MFMAs (2 k halves x 2 x 2 blocks of 32 x 32).  Fragments live in four register groups (the
+    // two A row blocks, the two B column blocks); every group is re-read ONE block before the block that needs it, in an
+    // order in which the group being overwritten is already dead -- so the transposing reads run under the previous
+    // block's MFMAs instead of in a read phase of their own.  Only the first two groups of a step are exposed.
+    // The next step's DMA instructions go between the blocks too (spread) instead of as a burst after the barrier.
+    uint4 F[4][NP];        // 0, 1: A row blocks;  2, 3: B column blocks
+    auto ldA = [&](int st, int mb, int ks) __attribute__((always_inline)) {
+        const unsigned char* Ax = smem + st * STAGE;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) F[mb][pl] = tr_frag(Ax + pl * PLANE, ks, wm * 64 + mb * 32);
+    };
+    auto ldB = [&](int st, int nb, int ks) __attribute__((always_inline)) {
+        const unsigned char* Bx = smem + st * STAGE + (1 + (wn >> 1)) * IMG;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) F[2 + nb][pl] = tr_frag(Bx + pl * PLANE, ks, (wn & 1) * 64 + nb * 32);
+    };
+    auto mm = [&](int mb, int nb) __attribute__((always_inline)) {
+        f32x16 c = acc[mb][nb];
+        if constexpr (NP == 3) {
+            c = mfma_bf16(F[mb][2], F[2 + nb][0], c);     // smallest terms first
+            c = mfma_bf16(F[mb][0], F[2 + nb][2], c);
+            c = mfma_bf16(F[mb][1], F[2 + nb][1], c);
+            c = mfma_bf16(F[mb][1], F[2 + nb][0], c);
+            c = mfma_bf16(F[mb][0], F[2 + nb][1], c);
+        }
+        c = mfma_bf16(F[mb][0], F[2 + nb][0], c);
+        acc[mb][nb] = c;
+    };
+    auto compute = [&](int st, bool spread) __attribute__((always_inline)) {
+        constexpr int NDMA = 3 * NP;
+        int slot = 0;
+        auto dmas = [&](int blk) __attribute__((always_inline)) {      // blocks 0..7: NDMA instructions dealt over them
+            const int upto = (NDMA * (blk + 1) + 7) / 8;
+            if (spread) {
+#pragma unroll
+                for (; slot < upto; ++slot) dma(slot, st ^ 1);
+            } else {
+                slot = upto;
+            }
+        };
+#define ISWM_SB() __builtin_amdgcn_sched_barrier(0)
+        ldA(st, 0, 0); ldB(st, 0, 0);
+        ISWM_SB(); ldB(st, 1, 0); ISWM_SB(); mm(0, 0); ISWM_SB(); dmas(0);
+        ISWM_SB(); ldA(st, 1, 0); ISWM_SB(); mm(0, 1); ISWM_SB(); dmas(1);
+        ISWM_SB(); ldA(st, 0, 1); ISWM_SB(); mm(1, 1); ISWM_SB(); dmas(2);     // A0 <- second k half
+        ISWM_SB(); ldB(st, 1, 1); ISWM_SB(); mm(1, 0); ISWM_SB(); dmas(3);     // B1 <- second k half
+        ISWM_SB(); ldB(st, 0, 1); ISWM_SB(); mm(0, 1); ISWM_SB(); dmas(4);     // B0 <- second k half
+        ISWM_SB(); ldA(st, 1, 1); ISWM_SB(); mm(0, 0); ISWM_SB(); dmas(5);     // A1 <- second k half
+        ISWM_SB(); mm(1, 0); ISWM_SB(); dmas(6);
+        ISWM_SB(); mm(1, 1); ISWM_SB(); dmas(7);
+        ISWM_SB();
+#undef ISWM_SB
+    };
+
+    {
+        int dbg_n = 0;
+        const bool dbg = a.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
+        auto stamp = [&](int k) __attribute__((always_inline)) {
+            if (dbg && dbg_n < 40 && lane == 0) a.dbg[(wave ? 256 : 0) + dbg_n * 6 + k] = __builtin_amdgcn_s_memtime();
+        };
+        bool have = next();
+        if (have) issue(0);
+        int st = 0;
+        while (have) {
+            stamp(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's pieces of the step have landed
+            stamp(1);
+            __builtin_amdgcn_s_barrier();            // everyone's have; the other buffer is free again
+            asm volatile("" ::: "memory");
+            stamp(2);
+            const bool more = next();
+            const bool spread = more && !a.burst && !(a.abl & 3);
+            if (more && !spread) issue(st ^ 1);
+            stamp(3);
+            if (!(a.abl & 2)) {
+                if (spread) compute(st, true);
+                else compute(st, false);
+            }
+            stamp(4);
+            st ^= 1;
+            have = more;
+            ++dbg_n;
+        }
+        stamp(0);
+    }
+
+    float* out = a.out + (size_t)split * a.Cout * a.Ktot;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int col = n0 + wn * 64 + nb * 32 + li;
+        const bool cok = col < a.Ktot;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < a.Cout) out[(size_t)row * a.Ktot + col] = acc[mb][nb][r];
+            }
+    }
+}
+
+// tile width along the (tap, ci) axis: 256 when that wastes little
+static int wgrad_pl_wide(int Ktot, int taps, int64_t P) {
+    static int force = -2;
+    if (force == -2) force = getenv("ISWM_WG_WIDE") ? atoi(getenv("ISWM_WG_WIDE")) : -1;
+    if (force >= 0) return force && Ktot > 128;
+    if (Ktot <= 128) return 0;
+    // the slabs of a launch are ~256 workgroups x one tile whatever the shape: 32 MB instead of 16 MB.  K x K filters and
+    // the 33 x 33 maps have the work per launch to pay for that (measured 1.05-1.4x); a 1 x 1 on a large map splits
+    // 64-128 ways over 1-4 tiles and does not (0.8-0.95x)
+    if (taps == 1 && P > 20000) return 0;
+    const int pad256 = (Ktot + 255) / 256 * 256, pad128 = (Ktot + 127) / 128 * 128;
+    return pad256 * 10 <= pad128 * 14;
+}
+
 // pixels per split (multiple of 32) and split count: minimise  rounds x (steps per workgroup + fixed cost) + slab traffic
-void plan_wgrad_pl(int Cout, int Ktot, int64_t P, int* nsplit, int* psplit) {
-    const int64_t tiles = (int64_t)((Cout + 127) / 128) * ((Ktot + 127) / 128);
-    const double step_us = 0.75;                                  // one 128x128x32 step of a CU
+void plan_wgrad_pl(int Cout, int Ktot, int taps, int64_t P, int* nsplit, int* psplit) {
+    const int wide = wgrad_pl_wide(Ktot, taps, P);
+    const int tn = wide ? 256 : 128;
+    const int64_t tiles = (int64_t)((Cout + 127) / 128) * ((Ktot + tn - 1) / tn);
+    const double step_us = wide ? 1.45 : 0.75;                    // one 128 x tn x 32 step of a CU
     const double slab_us = (double)Cout * Ktot * 8.0 / 4.0e6;     // one slab written + read at ~4 TB/s
     int64_t maxs = (P + 255) / 256;
     if (maxs > 256) maxs = 256;
@@ -289,10 +556,15 @@ void plan_wgrad_pl(int Cout, int Ktot, int64_t P, int* nsplit, int* psplit) {
     }
 }
 
-void launch_wgrad_pl(const WgArgs& a, int planes, hipStream_t s) {
+void launch_wgrad_pl(const WgArgs& a, int planes, int wide, hipStream_t s) {
     dim3 grid(a.MT * a.NT * a.nsplit), blk(512);
-    if (planes == 1) hipLaunchKernelGGL(k_wgrad_pl<1>, grid, blk, 0, s, a);
-    else hipLaunchKernelGGL(k_wgrad_pl<3>, grid, blk, 0, s, a);
+    if (wide) {
+        if (planes == 1) hipLaunchKernelGGL(k_wgrad_plw<1>, grid, blk, 0, s, a);
+        else hipLaunchKernelGGL(k_wgrad_plw<3>, grid, blk, 0, s, a);
+    } else {
+        if (planes == 1) hipLaunchKernelGGL(k_wgrad_pl<1>, grid, blk, 0, s, a);
+        else hipLaunchKernelGGL(k_wgrad_pl<3>, grid, blk, 0, s, a);
+    }
 }
 
 }  // namespace iswm
@@ -325,7 +597,7 @@ extern "C" int iswm_conv2d_wgrad_planes_ok(const iswm_conv_desc* d) {
 extern "C" size_t iswm_conv2d_wgrad_planes_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
     int ns, ps;
-    plan_wgrad_pl(d->Cout, d->KH * d->KW * d->Cin, (int64_t)d->N * d->Ho * d->Wo, &ns, &ps);
+    plan_wgrad_pl(d->Cout, d->KH * d->KW * d->Cin, d->KH * d->KW, (int64_t)d->N * d->Ho * d->Wo, &ns, &ps);
     if (ns <= 1) return 0;
     return (size_t)ns * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
 }
@@ -344,17 +616,26 @@ extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp,
     a.P = d->N * d->Ho * d->Wo;
     a.Ktot = d->KH * d->KW * d->Cin;
     a.MT = (d->Cout + 127) / 128;
-    a.NT = (a.Ktot + 127) / 128;
-    plan_wgrad_pl(d->Cout, a.Ktot, a.P, &a.nsplit, &a.psplit);
+    const int wide = wgrad_pl_wide(a.Ktot, d->KH * d->KW, a.P);
+    a.NT = wide ? (a.Ktot + 255) / 256 : (a.Ktot + 127) / 128;
+    plan_wgrad_pl(d->Cout, a.Ktot, d->KH * d->KW, a.P, &a.nsplit, &a.psplit);
     static int abl = -1;
     if (abl < 0) abl = getenv("ISWM_WG_ABL") ? atoi(getenv("ISWM_WG_ABL")) : 0;
     a.abl = abl;
+    a.dbg = g_conv_dbg;
+    {
+        static int b = -1, fv = -2;
+        if (b < 0) b = getenv("ISWM_WG_BURST") ? atoi(getenv("ISWM_WG_BURST")) : 0;
+        if (fv == -2) fv = getenv("ISWM_WG_VOTE") ? atoi(getenv("ISWM_WG_VOTE")) : -1;
+        a.burst = b;
+        a.vote = fv >= 0 ? fv : (d->pad >= 4 ? 1 : 0);
+    }
     a.always = (d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1) ? 1 : 0;
     const size_t need = iswm_conv2d_wgrad_planes_workspace(d);
     ISWM_REQUIRE(workspace_bytes >= need && (need == 0 || (workspace && aligned16(workspace))),
                  "wgrad_planes: workspace too small (%zu < %zu)", workspace_bytes, need);
     a.out = a.nsplit > 1 ? workspace : dw;
-    launch_wgrad_pl(a, planes, (hipStream_t)stream);
+    launch_wgrad_pl(a, planes, wide, (hipStream_t)stream);
     if (int e = check_launch("wgrad_planes")) return e;
     if (a.nsplit > 1) {
         launch_reduce_slabs(workspace, dw, (int64_t)d->Cout * a.Ktot / 4, a.nsplit, (hipStream_t)stream);
