@@ -813,10 +813,12 @@ static PatchArgs patch_args(const iswm_conv_desc* d, bool dgrad, int PH, int PW)
     return p;
 }
 
+namespace iswm { int wgrad_pl_is_wide(const iswm_conv_desc* d); }
+
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
     ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 7, "kernel_name: bad argument");
     if (kind == 7) {   // iswm_conv2d_wgrad_planes
-        snprintf(buf, buflen, "k_wgrad_pl<%d>", math_planes());
+        snprintf(buf, buflen, wgrad_pl_is_wide(d) ? "k_wgrad_plw<%d>" : "k_wgrad_pl<%d>", math_planes());
         return 0;
     }
     if (kind >= 5) {   // 5 / 6: iswm_conv2d_fwd_pl2 / iswm_conv2d_dgrad_pl2

@@ -39,7 +39,6 @@ struct WgArgs {
     int abl;                    // timing ablations (ISWM_WG_ABL): 1 no DMA, 2 no multiply
     int always;                 // 1: every gathered pixel is in bounds (1x1 stride-1 pad-0): no per-step culling vote
     unsigned long long* dbg;    // iswm_set_debug_buffer: per-step shader-clock stamps of workgroup 0 (tools/wgrad_timeline.py)
-    int burst;                  // 1: issue a step's DMA as one burst after the barrier instead of between the multiplies
     int vote;                   // 1: skip 32-pixel steps whose gathered pixels are ALL padding (workgroup-wide vote, one more
                                 // barrier per step: only worth it when the filter reaches far -- ASPP rates)
 };
@@ -410,7 +409,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
     // two A row blocks, the two B column blocks); every group is re-read ONE block before the block that needs it, in an
     // order in which the group being overwritten is already dead -- so the transposing reads run under the previous
     // block's MFMAs instead of in a read phase of their own.  Only the first two groups of a step are exposed.
-    // The next step's DMA instructions go between the blocks too (spread) instead of as a burst after the barrier.
     uint4 F[4][NP];        // 0, 1: A row blocks;  2, 3: B column blocks
     auto ldA = [&](int st, int mb, int ks) __attribute__((always_inline)) {
         const unsigned char* Ax = smem + st * STAGE;
@@ -434,28 +432,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
         c = mfma_bf16(F[mb][0], F[2 + nb][0], c);
         acc[mb][nb] = c;
     };
-    auto compute = [&](int st, bool spread) __attribute__((always_inline)) {
-        constexpr int NDMA = 3 * NP;
-        int slot = 0;
-        auto dmas = [&](int blk) __attribute__((always_inline)) {      // blocks 0..7: NDMA instructions dealt over them
-            const int upto = (NDMA * (blk + 1) + 7) / 8;
-            if (spread) {
-#pragma unroll
-                for (; slot < upto; ++slot) dma(slot, st ^ 1);
-            } else {
-                slot = upto;
-            }
-        };
+    // Where the next step's DMA instructions are issued -- as a burst after the barrier, dealt over the 8 blocks, or over
+    // blocks 0-3 by one wave of a SIMD and 4-7 by the other -- measured the same within noise (profiles/r02_notes.md), so
+    // the burst (least code) stays.
+    auto compute = [&](int st) __attribute__((always_inline)) {
 #define ISWM_SB() __builtin_amdgcn_sched_barrier(0)
         ldA(st, 0, 0); ldB(st, 0, 0);
-        ISWM_SB(); ldB(st, 1, 0); ISWM_SB(); mm(0, 0); ISWM_SB(); dmas(0);
-        ISWM_SB(); ldA(st, 1, 0); ISWM_SB(); mm(0, 1); ISWM_SB(); dmas(1);
-        ISWM_SB(); ldA(st, 0, 1); ISWM_SB(); mm(1, 1); ISWM_SB(); dmas(2);     // A0 <- second k half
-        ISWM_SB(); ldB(st, 1, 1); ISWM_SB(); mm(1, 0); ISWM_SB(); dmas(3);     // B1 <- second k half
-        ISWM_SB(); ldB(st, 0, 1); ISWM_SB(); mm(0, 1); ISWM_SB(); dmas(4);     // B0 <- second k half
-        ISWM_SB(); ldA(st, 1, 1); ISWM_SB(); mm(0, 0); ISWM_SB(); dmas(5);     // A1 <- second k half
-        ISWM_SB(); mm(1, 0); ISWM_SB(); dmas(6);
-        ISWM_SB(); mm(1, 1); ISWM_SB(); dmas(7);
+        ISWM_SB(); ldB(st, 1, 0); ISWM_SB(); mm(0, 0); ISWM_SB();
+        ISWM_SB(); ldA(st, 1, 0); ISWM_SB(); mm(0, 1); ISWM_SB();
+        ISWM_SB(); ldA(st, 0, 1); ISWM_SB(); mm(1, 1); ISWM_SB();     // A0 <- second k half
+        ISWM_SB(); ldB(st, 1, 1); ISWM_SB(); mm(1, 0); ISWM_SB();     // B1 <- second k half
+        ISWM_SB(); ldB(st, 0, 1); ISWM_SB(); mm(0, 1); ISWM_SB();     // B0 <- second k half
+        ISWM_SB(); ldA(st, 1, 1); ISWM_SB(); mm(0, 0); ISWM_SB();     // A1 <- second k half
+        ISWM_SB(); mm(1, 0); ISWM_SB();
+        ISWM_SB(); mm(1, 1); ISWM_SB();
         ISWM_SB();
 #undef ISWM_SB
     };
@@ -477,13 +467,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
             asm volatile("" ::: "memory");
             stamp(2);
             const bool more = next();
-            const bool spread = more && !a.burst && !(a.abl & 3);
-            if (more && !spread) issue(st ^ 1);
+            if (more) issue(st ^ 1);
             stamp(3);
-            if (!(a.abl & 2)) {
-                if (spread) compute(st, true);
-                else compute(st, false);
-            }
+            if (!(a.abl & 2)) compute(st);
             stamp(4);
             st ^= 1;
             have = more;
@@ -520,6 +506,10 @@ static int wgrad_pl_wide(int Ktot, int taps, int64_t P) {
     if (taps == 1 && P > 20000) return 0;
     const int pad256 = (Ktot + 255) / 256 * 256, pad128 = (Ktot + 127) / 128 * 128;
     return pad256 * 10 <= pad128 * 14;
+}
+
+int wgrad_pl_is_wide(const iswm_conv_desc* d) {
+    return wgrad_pl_wide(d->KH * d->KW * d->Cin, d->KH * d->KW, (int64_t)d->N * d->Ho * d->Wo);
 }
 
 // pixels per split (multiple of 32) and split count: minimise  rounds x (steps per workgroup + fixed cost) + slab traffic
@@ -624,10 +614,8 @@ extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp,
     a.abl = abl;
     a.dbg = g_conv_dbg;
     {
-        static int b = -1, fv = -2;
-        if (b < 0) b = getenv("ISWM_WG_BURST") ? atoi(getenv("ISWM_WG_BURST")) : 0;
+        static int fv = -2;
         if (fv == -2) fv = getenv("ISWM_WG_VOTE") ? atoi(getenv("ISWM_WG_VOTE")) : -1;
-        a.burst = b;
         a.vote = fv >= 0 ? fv : (d->pad >= 4 ? 1 : 0);
     }
     a.always = (d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1) ? 1 : 0;

@@ -74,6 +74,9 @@ os.environ["ISWM_X6_PATCH"] = "0"
 lib = _lib.load()
 GEN = int(os.environ.get("PL_GEN", "2"))
 print("conv math", lib.iswm_get_conv_math())
+if os.environ.get('PL_ONLY'):          # comma-separated case indices
+    CASES = [CASES[int(i)] for i in os.environ['PL_ONLY'].split(',')]
+NOCHECK = bool(os.environ.get('ISWM_WG_ABL') or os.environ.get('ISWM_PL_ABL'))     # ablations are wrong by design
 for (n, h, w, cin, cout, k, s, p, d) in (CASES[:NC_] if NC_ else CASES):
     torch.manual_seed(0)
     x = torch.randn(n, h, w, cin, device=dev)
@@ -103,7 +106,7 @@ for (n, h, w, cin, cout, k, s, p, d) in (CASES[:NC_] if NC_ else CASES):
         fl = g.flops()
         print("%-34s wgrad err=%.1e  fp32-in %.1f us (%.0f TF)  planes %.1f us (%.0f TF)  x%.2f" %
               (tag, err, r_med, fl / r_med * 1e-6, n_med, fl / n_med * 1e-6, r_med / n_med), flush=True)
-        assert err < 5e-6, "planes weight gradient differs"
+        assert NOCHECK or err < 5e-6, "planes weight gradient differs"
     if os.environ.get("PL_WGRAD_ONLY"):
         continue
     for kind in (0, 1):
