@@ -83,13 +83,27 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
     int i_m0 = 0, i_n0 = 0;
     int ihb[NRG], iwb[NRG], pb[NRG];
     const uint4* wpk = nullptr;
+    // Strided data gradient: rows are sorted by the parity class of their pixel (x6_row_pixel) and the tile sequence walks
+    // the four quarters of the M tiles HEAVIEST FIRST (a.porder, two bits per rank: a class is reached by 1, 2 or 4 of a 3x3's
+    // taps, by one or none of a 1x1's).  The persistent grid hands out tiles round-robin, so every workgroup gets its share
+    // of the heavy ones in the first rounds; dealing the quarters tile by tile (as the one-tile-per-workgroup kernels of
+    // round 1 do across XCD runs) gave each workgroup tiles of ONE class -- a quarter of the CUs did all of a 1x1's work.
+    auto par_mt = [&](int sq) __attribute__((always_inline)) -> int {
+        const int qn = a.MT >> 2, rem = a.MT & 3;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            k = (a.porder >> (2 * j)) & 3;
+            const int sz = qn + (k < rem ? 1 : 0);
+            if (sq < sz || j == 3) break;
+            sq -= sz;
+        }
+        return k * qn + (k < rem ? k : rem) + sq;
+    };
     auto load_tile = [&](int tile) __attribute__((always_inline)) {
         int mt = tile / a.NT;
         const int nt = tile - mt * a.NT;
-        if (par) {      // deal the four parity quarters of the M tiles across the XCD runs (see k_conv_x6)
-            const int qn = a.MT >> 2, rem = a.MT & 3, k = mt & 3, idx = mt >> 2;
-            mt = k * qn + (k < rem ? k : rem) + idx;
-        }
+        if (par) mt = par_mt(mt);
         i_m0 = mt * BM;
         i_n0 = nt * BN;
 #pragma unroll
@@ -221,10 +235,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         const uint4* wn_ = wpk + (size_t)k32n * (64 * NP);
         auto slot = [&](int sidx) __attribute__((always_inline)) {
             if (sidx < NB_SLOTS) {
-                bn.v[sidx / NP][sidx % NP] = wn_[sidx * 64];
+                if (!(a.abl & 1)) bn.v[sidx / NP][sidx % NP] = wn_[sidx * 64];
             } else if (sidx < NSLOTS) {
                 const int i = (sidx - NB_SLOTS) / NP, pp = (sidx - NB_SLOTS) % NP;
-                if (wave + 8 * i < RG) glds16b(aptr[i] + pp * pst[i], lds_base + (st ^ 1) * STAGE + pp * PLANE + (wave + 8 * i) * 1024);
+                if (wave + 8 * i < RG && !(a.abl & 2)) glds16b(aptr[i] + pp * pst[i], lds_base + (st ^ 1) * STAGE + pp * PLANE + (wave + 8 * i) * 1024);
             }
         };
         AFrag f0, f1;
@@ -259,10 +273,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
     const int lq = lane >> 4, lp = lane & 15;
     auto epilogue = [&](int tile, int m0, int n0, bool zero) __attribute__((always_inline)) {     // zero: a tile no tap reaches
         int mt = tile / a.NT;
-        if (par) {
-            const int qn = a.MT >> 2, rem = a.MT & 3, k = mt & 3, idx = mt >> 2;
-            mt = k * qn + (k < rem ? k : rem) + idx;
-        }
+        if (par) mt = par_mt(mt);
         const int col = n0 + 16 * wn + 4 * lq;
         const bool cok = col < NC;
         if (DGRAD && a.accumulate && zero) return;           // ... adds nothing
@@ -473,7 +484,23 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
         if (const char* g = getenv("ISWM_PL2_GRID")) ncu = atoi(g) > 0 ? atoi(g) : ncu;
     }
     a.psplit = parity ? 0 : 1;
+    {   // quarters of the parity-sorted rows, heaviest first (class k = 2 * (row parity) + column parity)
+        int wgt[4], ord[4] = {0, 1, 2, 3};
+        for (int k = 0; k < 4; ++k) {
+            int ch = 0, cw = 0;
+            for (int kh = 0; kh < a.KH; ++kh) ch += (((k >> 1) + a.pad - kh * a.dil) & 1) == 0;
+            for (int kw = 0; kw < a.KW; ++kw) cw += (((k & 1) + a.pad - kw * a.dil) & 1) == 0;
+            wgt[k] = ch * cw;
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j)
+                if (wgt[ord[j]] > wgt[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+        a.porder = ord[0] | (ord[1] << 2) | (ord[2] << 4) | (ord[3] << 6);
+    }
     a.dbg = g_conv_dbg;
+    static int abl = -1;
+    if (abl < 0) abl = getenv("ISWM_PL2_ABL") ? atoi(getenv("ISWM_PL2_ABL")) : 0;
+    a.abl = abl;
     static int burst = -1;
     if (burst < 0) burst = (getenv("ISWM_PL2_BURST") && atoi(getenv("ISWM_PL2_BURST"))) ? 1 : 0;
     a.nsplit = burst;
