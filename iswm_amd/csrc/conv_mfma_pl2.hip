@@ -241,26 +241,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
                 if (wave + 8 * i < RG && !(a.abl & 2)) glds16b(aptr[i] + pp * pst[i], lds_base + (st ^ 1) * STAGE + pp * PLANE + (wave + 8 * i) * 1024);
             }
         };
-        AFrag f0, f1;
-        aload(f0, 0);
+        // fragments are read TWO row blocks ahead of their multiply, with the order pinned: left to itself hipcc sinks two
+        // of a block's three reads behind the 4th MFMA of the previous block and waits for them (lgkmcnt(0)) two MFMAs
+        // later -- 32 cycles of cover for a ~100-cycle LDS round trip, at every row block
+        AFrag f[3];
+        aload(f[0], 0);
+        if (2 * RBW > 1) aload(f[1], 1);
 #pragma unroll
-        for (int idx = 0; idx < 2 * RBW; idx += 2) {
-            if (idx + 1 < 2 * RBW) aload(f1, idx + 1);
-            mul(f0, idx);
+        for (int idx = 0; idx < 2 * RBW; ++idx) {
+            if (idx + 2 < 2 * RBW) aload(f[(idx + 2) % 3], idx + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(f[idx % 3], idx);
             if (more) {
 #pragma unroll
                 for (int q = 0; q < PER; ++q) slot(idx * PER + q);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (idx + 1 < 2 * RBW) {
-                if (idx + 2 < 2 * RBW) aload(f0, idx + 2);
-                mul(f1, idx + 1);
-                if (more) {
-#pragma unroll
-                    for (int q = 0; q < PER; ++q) slot((idx + 1) * PER + q);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         if (more) {
 #pragma unroll
@@ -418,23 +414,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             stamp(0);
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's DMA pieces and weight fragments landed
             stamp(1);
-            __builtin_amdgcn_s_barrier();                // ... everyone's did; the other stage buffer is free
+            if (!(a.abl & 4)) __builtin_amdgcn_s_barrier();                // ... everyone's did; the other stage buffer is free
             asm volatile("" ::: "memory");
             stamp(2);
             bool more = next_in_tile();
             const bool last = !more;                      // the stage in hand is the last of its tile
             if (last) more = next_tile_stage();
-            if (a.nsplit) {                    // tuning switch ISWM_PL2_BURST=1: all loads of the next stage at the top of this one
-                if (more) {
-                    bload(bn, tap * (GC >> 5) + 2 * cc);
-                    issueA(st ^ 1);
-                }
-                compute(st, bc, false, bn, 0);
-            } else {
-                stamp(3);
-                compute(st, bc, more, bn, more ? tap * (GC >> 5) + 2 * cc : 0);
-                stamp(4);
-            }
+            stamp(3);
+            compute(st, bc, more, bn, more ? tap * (GC >> 5) + 2 * cc : 0);
+            stamp(4);
             if (last) {
                 epilogue(c_tile, c_m0, c_n0, false);
                 c_tile = i_tile; c_m0 = i_m0; c_n0 = i_n0;
@@ -501,9 +489,6 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
     static int abl = -1;
     if (abl < 0) abl = getenv("ISWM_PL2_ABL") ? atoi(getenv("ISWM_PL2_ABL")) : 0;
     a.abl = abl;
-    static int burst = -1;
-    if (burst < 0) burst = (getenv("ISWM_PL2_BURST") && atoi(getenv("ISWM_PL2_BURST"))) ? 1 : 0;
-    a.nsplit = burst;
     const int nc = dgrad ? a.Cin : a.Cout;
     const bool narrow = nc <= 64;
     a.MT = (a.M + rbw * 16 - 1) / (rbw * 16);
