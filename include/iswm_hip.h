@@ -158,6 +158,24 @@ int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int64_t plane_s
                         const float* bias, float* y, float* stat_partials, iswm_stream_t stream);
 int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
                           float* dx, int accumulate, iswm_stream_t stream);
+/* The same data gradient, also emitting the first pass of the BatchNorm backward that CONSUMES dx (the BatchNorm of the stage
+ * whose activation the conv read -- reference resnet.py:103-118: bn1 / bn2 of a Bottleneck): per tile row t and input channel c
+ *   partials[0][t][c] = sum dz,  partials[1][t][c] = sum dz * xhat,   dz = dx * [ReLU pattern],  xhat = (y - mean) * invstd
+ * over the finished dx (after accumulation).  y: that stage's raw conv output [N*H*W][ldy]; relu 0 = no activation, 2 = pattern
+ * recomputed as (y - mean) * mask_scale + mask_shift > 0, exactly as iswm_bn_backward does.  partials: 2 * tiles * Cin doubles,
+ * tiles = iswm_conv2d_dgrad_pl2_stat_tiles(d).  iswm_bn_backward_stats_pl then runs only the finalize and apply passes
+ * (8 bytes per element of HBM traffic less than iswm_bn_backward_pl). */
+int iswm_conv2d_dgrad_pl2_stat_tiles(const iswm_conv_desc* d);
+int iswm_conv2d_dgrad_pl2_bn(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk, float* dx,
+                             int accumulate, const float* y, int ldy, const float* mean, const float* invstd,
+                             const float* mask_scale, const float* mask_shift, int relu, double* partials, int tiles,
+                             iswm_stream_t stream);
+int iswm_bn_backward_stats_pl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps, const float* y, int ldy,
+                              int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                              const float* mask_scale, const float* mask_shift, int relu, int training, float* dgamma,
+                              float* dbeta, void* dy, int lddy, int64_t dy_ps, float* dres, int lddres,
+                              const double* partials, int tiles, void* workspace, size_t workspace_bytes,
+                              iswm_stream_t stream);
 /* weight gradient with BOTH operands pre-split (x: planes of the conv input, pitch d->ldx; dy: planes of the gradient of
  * the conv output, pitch d->ldy; pitches and plane strides in bf16 elements).  Needs Cin % 8 == 0 and Cout % 8 == 0
  * (iswm_conv2d_wgrad_planes_ok); same result layout, workspace protocol and call sites as iswm_conv2d_wgrad. */

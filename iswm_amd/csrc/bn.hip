@@ -550,11 +550,13 @@ extern "C" int iswm_bn_backward(const float* dout, int ldd, const float* out, in
                                training, dgamma, dbeta, dy, lddy, 0, dres, lddres, workspace, workspace_bytes, stream);
 }
 
-extern "C" int iswm_bn_backward_pl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps, const float* y,
-                                   int ldy, int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
-                                   const float* mask_scale, const float* mask_shift, int relu, int training,
-                                   float* dgamma, float* dbeta, void* dy, int lddy, int64_t dy_ps, float* dres,
-                                   int lddres, void* workspace, size_t workspace_bytes, iswm_stream_t stream) {
+// ready_partials != nullptr: the reduction pass was done by the producer of dout (iswm_conv2d_dgrad_pl2_bn)
+static int bn_backward_impl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps, const float* y,
+                            int ldy, int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                            const float* mask_scale, const float* mask_shift, int relu, int training,
+                            float* dgamma, float* dbeta, void* dy, int lddy, int64_t dy_ps, float* dres,
+                            int lddres, void* workspace, size_t workspace_bytes, const double* ready_partials,
+                            int ready_tiles, iswm_stream_t stream) {
     if (int e = chk_rows("bn_backward", M, C, ldy)) return e;
     if (int e = chk_ps("bn_backward(dy)", dy, M, lddy, dy_ps)) return e;
     if (out) if (int e = chk_ps("bn_backward(out)", out, M, ldo, out_ps)) return e;
@@ -570,11 +572,12 @@ extern "C" int iswm_bn_backward_pl(const float* dout, int ldd, const void* out, 
                  "bn_backward: bad pitch");
     ISWM_REQUIRE(workspace_bytes >= iswm_bn_bwd_workspace(M, C) && aligned16(workspace),
                  "bn_backward: workspace too small");
-    const int tiles = iswm_colstat_tiles(M);
-    double* partials = (double*)workspace;
-    double* sums = partials + (size_t)2 * tiles * C;
+    const int tiles = ready_partials ? ready_tiles : iswm_colstat_tiles(M);
+    const double* partials = ready_partials ? ready_partials : (const double*)workspace;
+    double* sums = (double*)workspace + (size_t)2 * iswm_colstat_tiles(M) * C;
     hipStream_t s = (hipStream_t)stream;
-    {
+    if (!ready_partials) {
+        double* partials = (double*)workspace;
         RowPlan p = plan_rows(M, C, tiles);
         dim3 grid(p.rowblocks, p.colblocks), blk(256);
 #define RLAUNCH(R, D)                                                                                           \
@@ -628,6 +631,31 @@ extern "C" int iswm_bn_backward_pl(const float* dout, int ldd, const void* out, 
     }
 #undef LAUNCH
     return check_launch("bn_bwd_apply");
+}
+
+extern "C" int iswm_bn_backward_pl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps, const float* y,
+                                   int ldy, int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
+                                   const float* mask_scale, const float* mask_shift, int relu, int training,
+                                   float* dgamma, float* dbeta, void* dy, int lddy, int64_t dy_ps, float* dres,
+                                   int lddres, void* workspace, size_t workspace_bytes, iswm_stream_t stream) {
+    return bn_backward_impl(dout, ldd, out, ldo, out_ps, y, ldy, M, C, mean, invstd, gamma, mask_scale, mask_shift, relu,
+                            training, dgamma, dbeta, dy, lddy, dy_ps, dres, lddres, workspace, workspace_bytes, nullptr, 0,
+                            stream);
+}
+
+/* iswm_bn_backward_pl whose first pass (sum dz, sum dz * xhat over the pixels) was already taken by the kernel that produced
+ * dout: partials = [2][tiles][C] doubles as written by iswm_conv2d_dgrad_pl2_bn.  Finalize + apply only. */
+extern "C" int iswm_bn_backward_stats_pl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps,
+                                         const float* y, int ldy, int64_t M, int C, const float* mean,
+                                         const float* invstd, const float* gamma, const float* mask_scale,
+                                         const float* mask_shift, int relu, int training, float* dgamma, float* dbeta,
+                                         void* dy, int lddy, int64_t dy_ps, float* dres, int lddres,
+                                         const double* partials, int tiles, void* workspace, size_t workspace_bytes,
+                                         iswm_stream_t stream) {
+    ISWM_REQUIRE(partials && tiles > 0 && aligned16(partials), "bn_backward_stats: bad partials");
+    return bn_backward_impl(dout, ldd, out, ldo, out_ps, y, ldy, M, C, mean, invstd, gamma, mask_scale, mask_shift, relu,
+                            training, dgamma, dbeta, dy, lddy, dy_ps, dres, lddres, workspace, workspace_bytes, partials,
+                            tiles, stream);
 }
 
 /* column sums of per-tile partials (bias gradient of a conv with bias): out[c] = sum_t partials[0][t][c] */

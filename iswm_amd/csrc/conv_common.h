@@ -8,6 +8,19 @@ namespace iswm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Statistics of the BatchNorm backward pass that consumes a data gradient, taken in the data-gradient kernel's epilogue
+// (iswm_conv2d_dgrad_pl2_bn): per tile row and channel  sum(dz), sum(dz * xhat)  with  dz = dx * [ReLU pattern],
+// xhat = (y - mean) * invstd  of the PRODUCER stage whose activation dx is the gradient of.
+struct BnFuse {
+    const float* y;            // raw conv output of the producer stage at the data gradient's pixels [P][ldy]
+    const float* mean;
+    const float* invstd;
+    const float* mscale;       // relu == 2: pattern recomputed as (y - mean) * mscale + mshift > 0
+    const float* mshift;
+    double* part;              // [2][tiles][C]; nullptr = off
+    int ldy, relu;
+};
+
 struct ConvArgs {
     const float* x;
     const float* w;
@@ -24,6 +37,7 @@ struct ConvArgs {
     long long xps;   // plane kernels (conv_mfma_pl.hip): byte stride between the bf16 planes of the gathered operand
     int porder;                // strided dgrad of the planes kernels: the four parity quarters of the M tiles, heaviest first (2 bits each)
     int abl;                   // timing ablations of the planes kernels (ISWM_PL2_ABL: 1 no weight loads, 2 no activation DMA): wrong results by design
+    BnFuse bnf;                // planes data gradient: fused BatchNorm-backward statistics (part == nullptr: off)
     unsigned long long* dbg;   // diagnostic builds only (iswm_set_debug_buffer): per-stage s_memtime stamps of workgroup 0, wave 0
 };
 

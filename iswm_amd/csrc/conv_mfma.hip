@@ -1179,8 +1179,8 @@ extern "C" int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int6
     return check_launch("conv_fwd_pl2");
 }
 
-extern "C" int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
-                                     float* dx, int accumulate, iswm_stream_t stream) {
+static int dgrad_pl2_impl(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk, float* dx,
+                          int accumulate, const BnFuse* f, iswm_stream_t stream) {
     if (int e = validate(d)) return e;
     ISWM_REQUIRE(dyp && wpk && dx, "conv_dgrad_pl2: null pointer");
     ISWM_REQUIRE(aligned16(dyp) && aligned16(wpk) && aligned16(dx), "conv_dgrad_pl2: pointers must be 16-byte aligned");
@@ -1191,8 +1191,46 @@ extern "C" int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, i
     a.xps = plane_stride * 2;
     a.M = d->N * d->H * d->W;
     a.Ktot = d->KH * d->KW * d->Cout;
+    if (f) a.bnf = *f;
     ISWM_REQUIRE(launch_conv_pl2(a, (hipStream_t)stream, true, math_planes(), conv_pl2_pick_rbw(a.M, d->Cin)), "conv_dgrad_pl2: no kernel for this configuration");
     return check_launch("conv_dgrad_pl2");
+}
+
+extern "C" int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
+                                     float* dx, int accumulate, iswm_stream_t stream) {
+    return dgrad_pl2_impl(d, dyp, plane_stride, wpk, dx, accumulate, nullptr, stream);
+}
+
+/* tile rows of the planes data gradient = first dimension of the statistics it can emit for the consumer BatchNorm backward */
+extern "C" int iswm_conv2d_dgrad_pl2_stat_tiles(const iswm_conv_desc* d) {
+    if (!d || d->Cin <= 0) return 0;
+    const int64_t M = (int64_t)d->N * d->H * d->W;
+    const int rbw = conv_pl2_pick_rbw(M, d->Cin);
+    const int wm = d->Cin <= 64 ? 2 : 1;                 // narrow tiles: (rbw / 2) blocks x 2 wave rows
+    const int64_t mt = (M + rbw * 16 - 1) / (rbw * 16);
+    return (int)(mt * wm);
+}
+
+/* iswm_conv2d_dgrad_pl2 that also emits, per tile row and input channel, the two sums the BatchNorm backward of the stage
+ * that PRODUCED the conv's input needs over the finished dx (after accumulation):  partials[0][t][c] = sum dz,
+ * partials[1][t][c] = sum dz * xhat,  dz = dx * [ReLU pattern], xhat = (y - mean) * invstd.  relu: 0 none, 2 pattern
+ * recomputed as (y - mean) * mask_scale + mask_shift > 0 (as iswm_bn_backward does).  y: the producer's raw conv output
+ * [N*H*W][ldy], Cin channels.  partials: 2 * tiles * Cin doubles, tiles = iswm_conv2d_dgrad_pl2_stat_tiles(d).  Feed them to
+ * iswm_bn_backward_pl with partial_tiles = tiles: it then skips its own reduction pass over dout and y. */
+extern "C" int iswm_conv2d_dgrad_pl2_bn(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
+                                        float* dx, int accumulate, const float* y, int ldy, const float* mean,
+                                        const float* invstd, const float* mask_scale, const float* mask_shift, int relu,
+                                        double* partials, int tiles, iswm_stream_t stream) {
+    ISWM_REQUIRE(d && y && mean && invstd && partials, "conv_dgrad_pl2_bn: null pointer");
+    ISWM_REQUIRE(relu == 0 || (relu == 2 && mask_scale && mask_shift), "conv_dgrad_pl2_bn: relu must be 0 or 2 (with mask_scale / mask_shift)");
+    ISWM_REQUIRE(d->Cin % 4 == 0 && ldy % 4 == 0 && ldy >= d->Cin && aligned16(y) && aligned16(mean) && aligned16(invstd),
+                 "conv_dgrad_pl2_bn: Cin %% 4, ldy %% 4, 16-byte aligned pointers");
+    ISWM_REQUIRE(tiles == iswm_conv2d_dgrad_pl2_stat_tiles(d), "conv_dgrad_pl2_bn: tiles %d != %d", tiles,
+                 iswm_conv2d_dgrad_pl2_stat_tiles(d));
+    BnFuse f{};
+    f.y = y; f.ldy = ldy; f.mean = mean; f.invstd = invstd; f.mscale = mask_scale; f.mshift = mask_shift; f.relu = relu;
+    f.part = partials;
+    return dgrad_pl2_impl(d, dyp, plane_stride, wpk, dx, accumulate, &f, stream);
 }
 
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {

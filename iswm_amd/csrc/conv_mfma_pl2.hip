@@ -272,7 +272,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         if (par) mt = par_mt(mt);
         const int col = n0 + 16 * wn + 4 * lq;
         const bool cok = col < NC;
-        if (DGRAD && a.accumulate && zero) return;           // ... adds nothing
+        const bool bnf = DGRAD && a.bnf.part != nullptr;
+        if (DGRAD && a.accumulate && zero && !bnf) return;           // ... adds nothing
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!DGRAD && a.bias != nullptr && cok) bv = *reinterpret_cast<const float4*>(a.bias + col);
         if (DGRAD && par) {
@@ -285,21 +286,93 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             }
             __syncthreads();
         }
+        float4 f_mu = bv, f_is = bv, f_sc = bv, f_sh = bv;
+        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bnf && cok) {
+            f_mu = *reinterpret_cast<const float4*>(a.bnf.mean + col);
+            f_is = *reinterpret_cast<const float4*>(a.bnf.invstd + col);
+            if (a.bnf.relu == 2) {
+                f_sc = *reinterpret_cast<const float4*>(a.bnf.mscale + col);
+                f_sh = *reinterpret_cast<const float4*>(a.bnf.mshift + col);
+            }
+        }
+        // everything the epilogue READS (the gradient accumulated so far, the producer's conv output for the fused
+        // statistics) is fetched for all row blocks before the first store: hipcc cannot move a load above a store that
+        // may alias it, and one load-then-store per row block costs a memory round trip per block
+        // (in two halves of the row blocks: 2 x RBW x 4 more live registers do not fit beside the RBW = 10 accumulators)
+        constexpr int EH = (RBW + 1) / 2;
 #pragma unroll
-        for (int rb = 0; rb < RBW; ++rb) {
-            const int lrw = (wm * RBW + rb) * 16 + lp;
-            const int row = m0 + lrw;
-            if (cok && row < a.M) {
-                const int pix = (DGRAD && par) ? rowpix[DGRAD ? lrw : 0] : row;
-                float4* o = reinterpret_cast<float4*>(&a.y[(size_t)pix * a.ldy + col]);
-                float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
-                if (DGRAD && a.accumulate) {
-                    const float4 old = *o;
-                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-                } else {
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        for (int h0 = 0; h0 < RBW; h0 += EH) {
+            float4 oldv[EH], yvv[EH];
+            if constexpr (DGRAD) {
+#pragma unroll
+                for (int j = 0; j < EH; ++j) {
+                    const int rb = h0 + j;
+                    const int lrw = (wm * RBW + rb) * 16 + lp;
+                    const int row = m0 + lrw;
+                    oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    yvv[j] = oldv[j];
+                    if (rb < RBW && cok && row < a.M) {
+                        const int pix = par ? rowpix[lrw] : row;
+                        if (a.accumulate) oldv[j] = *reinterpret_cast<const float4*>(&a.y[(size_t)pix * a.ldy + col]);
+                        if (bnf) yvv[j] = *reinterpret_cast<const float4*>(a.bnf.y + (size_t)pix * a.bnf.ldy + col);
+                    }
                 }
-                *o = v;
+            }
+#pragma unroll
+            for (int j = 0; j < EH; ++j) {
+                const int rb = h0 + j;
+                if (rb >= RBW) continue;
+                const int lrw = (wm * RBW + rb) * 16 + lp;
+                const int row = m0 + lrw;
+                if (cok && row < a.M) {
+                    const int pix = (DGRAD && par) ? rowpix[DGRAD ? lrw : 0] : row;
+                    float4* o = reinterpret_cast<float4*>(&a.y[(size_t)pix * a.ldy + col]);
+                    float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+                    if (DGRAD && a.accumulate) {
+                        const float4 old = oldv[j];
+                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    } else {
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    }
+                    if (!(DGRAD && a.accumulate && zero)) *o = v;
+                    if (bnf) {
+                        // same expressions as k_bn_bwd_reduce (bn.hip): the ReLU pattern from the forward's own formula
+                        const float4 yv = yvv[j];
+                        float4 g = v;
+                        if (a.bnf.relu == 2) {
+                            g.x = (yv.x - f_mu.x) * f_sc.x + f_sh.x > 0.f ? g.x : 0.f;
+                            g.y = (yv.y - f_mu.y) * f_sc.y + f_sh.y > 0.f ? g.y : 0.f;
+                            g.z = (yv.z - f_mu.z) * f_sc.z + f_sh.z > 0.f ? g.z : 0.f;
+                            g.w = (yv.w - f_mu.w) * f_sc.w + f_sh.w > 0.f ? g.w : 0.f;
+                        }
+                        fs[0] += g.x; fs[1] += g.y; fs[2] += g.z; fs[3] += g.w;
+                        fq[0] += g.x * ((yv.x - f_mu.x) * f_is.x); fq[1] += g.y * ((yv.y - f_mu.y) * f_is.y);
+                        fq[2] += g.z * ((yv.z - f_mu.z) * f_is.z); fq[3] += g.w * ((yv.w - f_mu.w) * f_is.w);
+                    }
+                }
+            }
+        }
+        if (bnf) {
+            // <= RBW pixels per lane in fp32, the 16 lanes of a channel quad and everything after in double
+            double ds[4], dq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ds[r] = (double)fs[r];
+                dq[r] = (double)fq[r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    ds[r] += __shfl_xor(ds[r], m);
+                    dq[r] += __shfl_xor(dq[r], m);
+                }
+            }
+            if (lp == 0 && cok) {
+                const size_t T = (size_t)a.MT * WM, prow = (size_t)mt * WM + wm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a.bnf.part[prow * NC + col + r] = ds[r];
+                    a.bnf.part[(T + prow) * NC + col + r] = dq[r];
+                }
             }
         }
         if (!DGRAD && a.stats != nullptr) {

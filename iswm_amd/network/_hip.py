@@ -389,8 +389,18 @@ def _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residu
     return o, ctx
 
 
-def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
-    """Returns (dx, dres): dres is the gradient of the residual input (if any)."""
+def _bn_stats_request(up):
+    """`up` = ctx of the stage that produced this stage's input, when ITS BatchNorm backward is the only consumer of the dx this
+    stage returns: the planes data gradient then takes that backward's reduction pass in its epilogue (ops.BnStats)."""
+    if up is None or not ops.planes_on() or up.get("res") or up.get("bn_stats") is not None:
+        return None
+    if ops._relu_code(up["relu"]) not in (0, 1) or not ops._BN_MASK_FROM_Y:
+        return None
+    return ops.BnStats(up["y"], up["coef"], up["relu"])
+
+
+def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False, up=None):
+    """Returns (dx, dres): dres is the gradient of the residual input (if any).  up: see _bn_stats_request."""
     x, y, o, g = ctx["x"], ctx["y"], ctx["out"], ctx["g"]
     sep = ctx.get("sep")
     if sep is not None:
@@ -401,7 +411,7 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
     # dy goes out pre-split when the data-gradient kernel takes planes (and the conv is not a depthwise one)
     dyp = (not ctx.get("dw")) and ops.planes_conv_ok(conv.cin_p, conv.cout_p, 1)
     dy, dres = ops.bn_backward(ops.as_f32(dout), o if ctx["relu"] else None, y, ctx["coef"], gw, ctx["relu"], ctx["training"],
-                               dgamma, dbeta, want_dres=ctx["res"], dy_planes=dyp)
+                               dgamma, dbeta, want_dres=ctx["res"], dy_planes=dyp, stats=ctx.pop("bn_stats", None))
     if gw.requires_grad:
         sink.done(gw)
     if gb.requires_grad:
@@ -416,7 +426,11 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False):
         dmid = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), wpk=conv.packed(1), wpk2=conv.packed2(1))
         return sep.body[0].bwd(dmid, sink, need_dx, dx, accumulate), dres
     if need_dx:
-        dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=conv.packed(1), wpk2=conv.packed2(1))
+        req = _bn_stats_request(up) if (up is not None and tuple(up["y"].shape) == tuple(x.shape)) else None
+        dx = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=conv.packed(1), wpk2=conv.packed2(1),
+                              bn_stats=req)
+        if req is not None and req.partials is not None:
+            up["bn_stats"] = req
     else:
         dx = None
     return dx, dres

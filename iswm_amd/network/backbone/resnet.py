@@ -61,8 +61,9 @@ class Bottleneck(_hip.HipModule):
     def bwd(self, dout, sink, need_dx=True):
         c1, c2, c3, cd = self._saved
         self._saved = None
-        d2, dres = _hip.cba_bwd(self.conv3, self.bn3, c3, dout, sink)
-        d1, _ = _hip.cba_bwd(self.conv2, self.bn2, c2, d2, sink)
+        # conv3's / conv2's data gradients are consumed by bn2's / bn1's backward alone: they take its reduction pass along
+        d2, dres = _hip.cba_bwd(self.conv3, self.bn3, c3, dout, sink, up=c2)
+        d1, _ = _hip.cba_bwd(self.conv2, self.bn2, c2, d2, sink, up=c1)
         if cd is not None:
             # conv1 (1x1, stride 1) writes every input pixel; the strided downsample conv then only touches the
             # pixels it reaches (its data gradient skips the other parity classes when accumulating)

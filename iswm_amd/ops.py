@@ -361,9 +361,22 @@ def planes_conv_ok(cin, cout, kind):
     return planes_on() and (cout if kind else cin) % 64 == 0
 
 
-def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=None, wpk2=None):
+class BnStats(object):
+    """Request / result of the BatchNorm-backward statistics a planes data gradient can take in its epilogue: `y`, `coef`
+    (scale, shift, mean, invstd) and `relu` describe the stage that PRODUCED the conv's input (whose BatchNorm backward will
+    consume dx); conv2d_dgrad fills `partials`, `tiles` when its kernel supports the fusion (they stay None otherwise)."""
+
+    def __init__(self, y, coef, relu):
+        self.y, self.coef, self.relu = y, coef, relu
+        self.partials, self.tiles = None, 0
+
+
+_BN_FUSE = os.environ.get("ISWM_BN_FUSE", "1") != "0"      # tuning switch: 0 = BatchNorm backward always reduces itself
+
+
+def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=None, wpk2=None, bn_stats=None):
     """dx (=|+=) conv^T(dy, w).  x_like_shape = (N,H,W,Cin) of the conv input.  wpk: weight already packed for the
-    data-gradient kernel (wpk2: for the planes kernel)."""
+    data-gradient kernel (wpk2: for the planes kernel).  bn_stats: a BnStats to fill (planes kernel only)."""
     _check_w(w_ohwi, g)
     if dx is None:
         assert not accumulate
@@ -377,6 +390,17 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=Non
             if wpk2 is None:
                 wpk2 = torch.empty((nb2 // 4,), dtype=torch.float32, device=dx.device)
                 call("iswm_conv2d_pl2_pack_weights", ctypes.byref(d), 1, _p(w_ohwi), _p(wpk2), _stream())
+            if bn_stats is not None and _BN_FUSE and g.cin % 4 == 0:
+                b = bn_stats
+                tiles = _lib.load().iswm_conv2d_dgrad_pl2_stat_tiles(ctypes.byref(d))
+                part = torch.empty((2, tiles, g.cin), dtype=torch.float64, device=dx.device)
+                masky = _relu_code(b.relu) == 1
+                with _timed(d, 6, g):
+                    call("iswm_conv2d_dgrad_pl2_bn", ctypes.byref(d), _p(dy.t), ps, _p(wpk2), _p(dx), int(bool(accumulate)),
+                         _p(b.y), rows(b.y)[2], _p(b.coef[2]), _p(b.coef[3]), _p(b.coef[0]) if masky else None,
+                         _p(b.coef[1]) if masky else None, 2 if masky else 0, _p(part), tiles, _stream())
+                b.partials, b.tiles = part, tiles
+                return dx
             with _timed(d, 6, g):
                 call("iswm_conv2d_dgrad_pl2", ctypes.byref(d), _p(dy.t), ps, _p(wpk2), _p(dx), int(bool(accumulate)), _stream())
             return dx
@@ -531,10 +555,11 @@ def bn_apply(y, coef, relu, residual=None, out=None, planes=False):
 _BN_MASK_FROM_Y = os.environ.get("ISWM_BN_MASKY", "1") != "0"     # tuning switch
 
 
-def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_dres=False, dy=None, dy_planes=False):
+def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_dres=False, dy=None, dy_planes=False,
+                stats=None):
     """Returns (dy, dres|None); writes dgamma / dbeta (length-C fp32 tensors).  `out` (the saved activation, for the
     ReLU pattern) may be Planes; dy is written as Planes when dy_planes (the conv's data / weight gradient kernels
-    take it pre-split)."""
+    take it pre-split).  stats: a filled BnStats from the data gradient that produced dout -- the reduction pass is skipped."""
     m, c, ldy = rows(y)
     _, _, ldd = rows(dout)
     po, ldo, pso = None, 0, 0
@@ -549,6 +574,12 @@ def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_d
     # ReLU without a residual: hand over the forward's scale / shift so the sign pattern is recomputed from y and the
     # saved output is never read (a residual stage's pattern depends on the identity tensor: read `out` there)
     masky = _relu_code(relu) == 1 and not want_dres and _BN_MASK_FROM_Y
+    if stats is not None and stats.partials is not None:
+        call("iswm_bn_backward_stats_pl", _p(dout), ldd, _p(po), ldo, pso, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
+             _p(coef[0]) if masky else None, _p(coef[1]) if masky else None,
+             _relu_code(relu), int(bool(training)), _p(dgamma), _p(dbeta), _p(pdy), lddy, psdy, _p(dres),
+             rows(dres)[2] if dres is not None else 0, _p(stats.partials), stats.tiles, _p(ws), need, _stream())
+        return dy, dres
     call("iswm_bn_backward_pl", _p(dout), ldd, _p(po), ldo, pso, _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma),
          _p(coef[0]) if masky else None, _p(coef[1]) if masky else None,
          _relu_code(relu), int(bool(training)), _p(dgamma), _p(dbeta), _p(pdy), lddy, psdy, _p(dres),

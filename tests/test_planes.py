@@ -190,6 +190,45 @@ def test_network_on_planes_matches_network_on_fp32_activations(monkeypatch):
         assert float((a - b).norm() / (b.norm() + 1e-30)) <= 5e-2, k
 
 
+def test_batchnorm_backward_statistics_taken_by_the_data_gradient(monkeypatch):
+    """The reduction pass of a BatchNorm backward (sum dz, sum dz*xhat) taken in the epilogue of the data gradient that
+    produces its input (iswm_conv2d_dgrad_pl2_bn -> iswm_bn_backward_stats_pl; bn1 / bn2 of every Bottleneck) against the
+    stand-alone pass: the same masks and the same per-element expressions, so parameter gradients agree to summation order."""
+    from iswm_amd import ops
+    from iswm_amd.network import modeling
+    from oracle.synth import ArchCfg, synth_images, synth_labels, synth_state_dict
+    if not ops.planes_on():
+        pytest.skip("planes are a bf16x6 feature")
+    sd = synth_state_dict(ArchCfg("deeplabv3plus", "resnet50", 2, 16))
+    m = modeling.deeplabv3plus_resnet50(num_classes=2, output_stride=16)
+    m.load_state_dict(sd, strict=True)
+    m.classifier.aspp.project[3].p = 0.0
+    m = m.to(dev()).train()
+    x = synth_images(4, 65, 65, seed=23).to(dev())
+    lab = synth_labels(4, 65, 65, seed=23, p_fg=0.2, p_ignore=0.05).to(dev())
+    w = torch.tensor([1.0, 3.0])
+    calls = []
+    real = ops.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(ops, "call", spy)
+    lg_a, loss_a, g_a = _step(m, x, lab, w)
+    fused = calls.count("iswm_bn_backward_stats_pl")
+    assert fused >= 32 and calls.count("iswm_conv2d_dgrad_pl2_bn") == fused      # 16 bottlenecks x (bn1, bn2)
+    m.load_state_dict(sd, strict=True)
+    monkeypatch.setattr(ops, "_BN_FUSE", False)
+    del calls[:]
+    lg_b, loss_b, g_b = _step(m, x, lab, w)
+    assert calls.count("iswm_bn_backward_stats_pl") == 0
+    assert torch.equal(lg_a, lg_b) and torch.equal(loss_a, loss_b)
+    for k in g_a:
+        a, b = g_a[k].double().flatten(), g_b[k].double().flatten()
+        assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 2e-5, k
+
+
 def test_stem_stage_vs_reference_golden():
     """stem.npz (generated from the reference's ResNet stem: conv 7x7/2 + BN + ReLU + max-pool on [2,3,65,65]) on the
     GPU: the stage output and the parameter gradients"""
