@@ -478,7 +478,21 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
         stamp(0);
     }
 
-    float* out = a.out + (size_t)split * a.Cout * a.Ktot;
+    if (a.nsplit > 1) {
+        // slab of this (split, tile) in ACCUMULATOR order: [wave][(mb, nb, q)][lane] float4 -- 16 whole-line stores per lane
+        // instead of 64 four-byte ones; k_reduce_slabs_frag sums the splits in that order and scatters the result into dw
+        float4* slab = reinterpret_cast<float4*>(a.out) + ((size_t)split * tiles + tile) * 8192 + (size_t)wave * 1024 + lane;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    slab[((mb * 2 + nb) * 4 + q) * 64] =
+                        make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
+        return;
+    }
+    float* out = a.out;
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -491,6 +505,42 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
                 const int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (cok && row < a.Cout) out[(size_t)row * a.Ktot + col] = acc[mb][nb][r];
             }
+    }
+}
+
+// sum of the accumulator-order slabs of k_wgrad_plw over the splits (fixed order: bit-reproducible), scattered into dw:
+// float4 f of tile t holds rows m0 + 64 wm + 32 mb + 8 q + 4 (lane >> 5) + 0..3 of column n0 + 64 wn + 32 nb + (lane & 31)
+__global__ __launch_bounds__(256) void k_reduce_slabs_frag(const float4* __restrict__ slabs, float* __restrict__ dw, int tiles,
+                                                           int NT, int nsplit, int Cout, int Ktot) {
+    const int64_t total = (int64_t)tiles * 8192;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = slabs[i];
+        int k = 1;
+        for (; k + 3 < nsplit; k += 4) {           // four splits in flight per thread
+            const float4 v0 = slabs[i + (int64_t)k * total], v1 = slabs[i + (int64_t)(k + 1) * total];
+            const float4 v2 = slabs[i + (int64_t)(k + 2) * total], v3 = slabs[i + (int64_t)(k + 3) * total];
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; k < nsplit; ++k) {
+            const float4 v = slabs[i + (int64_t)k * total];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int tile = (int)(i >> 13), f = (int)(i & 8191);
+        const int wave = f >> 10, j = (f >> 6) & 15, lane = f & 63;
+        const int mt = tile / NT, nt = tile - mt * NT;
+        const int wm = wave >> 2, wn = wave & 3, mb = j >> 3, nb = (j >> 2) & 1, q = j & 3;
+        const int col = nt * 256 + wn * 64 + nb * 32 + (lane & 31);
+        const int row = mt * 128 + wm * 64 + mb * 32 + 8 * q + 4 * (lane >> 5);
+        if (col < Ktot) {
+            float* o = dw + (size_t)row * Ktot + col;
+            if (row < Cout) o[0] = s.x;
+            if (row + 1 < Cout) o[(size_t)Ktot] = s.y;
+            if (row + 2 < Cout) o[(size_t)2 * Ktot] = s.z;
+            if (row + 3 < Cout) o[(size_t)3 * Ktot] = s.w;
+        }
     }
 }
 
@@ -587,9 +637,13 @@ extern "C" int iswm_conv2d_wgrad_planes_ok(const iswm_conv_desc* d) {
 extern "C" size_t iswm_conv2d_wgrad_planes_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
     int ns, ps;
-    plan_wgrad_pl(d->Cout, d->KH * d->KW * d->Cin, d->KH * d->KW, (int64_t)d->N * d->Ho * d->Wo, &ns, &ps);
+    const int Ktot = d->KH * d->KW * d->Cin;
+    const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+    plan_wgrad_pl(d->Cout, Ktot, d->KH * d->KW, P, &ns, &ps);
     if (ns <= 1) return 0;
-    return (size_t)ns * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
+    if (wgrad_pl_wide(Ktot, d->KH * d->KW, P))      // whole 128 x 256 tiles in accumulator order
+        return (size_t)ns * ((d->Cout + 127) / 128) * ((Ktot + 255) / 256) * 32768 * sizeof(float);
+    return (size_t)ns * d->Cout * Ktot * sizeof(float);
 }
 
 extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp, int64_t x_ps, const void* dyp, int64_t dy_ps,
@@ -626,7 +680,14 @@ extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp,
     launch_wgrad_pl(a, planes, wide, (hipStream_t)stream);
     if (int e = check_launch("wgrad_planes")) return e;
     if (a.nsplit > 1) {
-        launch_reduce_slabs(workspace, dw, (int64_t)d->Cout * a.Ktot / 4, a.nsplit, (hipStream_t)stream);
+        if (wide) {
+            const int tiles = a.MT * a.NT;
+            hipLaunchKernelGGL(k_reduce_slabs_frag, dim3(stream_grid((int64_t)tiles * 8192, 256)), dim3(256), 0,
+                               (hipStream_t)stream, reinterpret_cast<const float4*>(workspace), dw, tiles, a.NT, a.nsplit,
+                               d->Cout, a.Ktot);
+        } else {
+            launch_reduce_slabs(workspace, dw, (int64_t)d->Cout * a.Ktot / 4, a.nsplit, (hipStream_t)stream);
+        }
         return check_launch("wgrad_planes_reduce");
     }
     return 0;

@@ -124,7 +124,8 @@ def get_dataset(opts):
 def load_checkpoint(path):
     """torch.load that executes nothing from the file; the reference's checkpoints (train.py:567-582) carry numpy
     scalars inside val_score / best_score, which the weights-only unpickler admits once their types are allow-listed"""
-    allow = [np.core.multiarray.scalar if hasattr(np, "core") else None, np.dtype, np.float64, np.float32, np.int64]
+    _npcore = getattr(np, "_core", None) or getattr(np, "core", None)
+    allow = [_npcore.multiarray.scalar if _npcore is not None else None, np.dtype, np.float64, np.float32, np.int64]
     try:
         from numpy import dtypes as _npd
         allow += [getattr(_npd, n) for n in ("Float64DType", "Float32DType", "Int64DType") if hasattr(_npd, n)]
