@@ -36,7 +36,7 @@ struct ConvArgs {
     int accumulate;  // dgrad: dx += result instead of dx = result
     long long xps;   // plane kernels (conv_mfma_pl.hip): byte stride between the bf16 planes of the gathered operand
     int porder;                // strided dgrad of the planes kernels: the four parity quarters of the M tiles, heaviest first (2 bits each)
-    int abl;                   // timing ablations of the planes kernels (ISWM_PL2_ABL: 1 no weight loads, 2 no activation DMA): wrong results by design
+    int abl;                   // timing ablations of the planes kernels (ISWM_PL2_ABL: 1 no weight loads, 2 no activation DMA, 4 no stage barrier, 8 no fragment reads): wrong results by design
     BnFuse bnf;                // planes data gradient: fused BatchNorm-backward statistics (part == nullptr: off)
     unsigned long long* dbg;   // diagnostic builds only (iswm_set_debug_buffer): per-stage s_memtime stamps of workgroup 0, wave 0
 };

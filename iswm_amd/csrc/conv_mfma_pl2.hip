@@ -49,7 +49,7 @@ unsigned long long* g_conv_dbg = nullptr;        // iswm_set_debug_buffer
 // Tile = (16 * RBW * WM) rows x (128 / WM) columns; wave (wm, wn) owns rows [wm*16*RBW, +16*RBW) and columns 16*wn..+15.
 // PERSISTENT: the grid is min(tiles, CUs) workgroups; a workgroup walks tiles  it * gridDim + xcd_remap(blockIdx)  and its
 // stage pipeline runs across tile boundaries, so a tile's epilogue overlaps the DMA of the next tile's first stage.
-template <int RBW, int WM, int NP, bool DGRAD>
+template <int RBW, int WM, int NP, bool DGRAD, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
     const int GC = DGRAD ? a.Cout : a.Cin;     // channels of the gathered operand (per tap)
     const int NC = DGRAD ? a.Cin : a.Cout;     // output columns
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             pst[i] = ok ? a.xps : 0;
             any |= ok;
         }
+        // tiles no tap reaches only exist where the padding is deep (ASPP rates); elsewhere the workgroup-wide vote (a barrier
+        // and an LDS round trip per tap, with every wave waiting) would buy nothing: a tap that reads only the zero row just
+        // multiplies zeros
+        if (a.pad < 4 && a.stride == 1) return true;
         return __syncthreads_or(any) != 0;
     };
     int tap = -1, cc = nCC - 1;
@@ -209,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         // fragments of row block i+1 are read while block i is multiplied; the scheduling fences keep hipcc from
         // hoisting all 2 * RBW * NP fragment reads of a stage to its top (216 VGPRs for RBW = 9)
         auto aload = [&](AFrag& f, int idx) __attribute__((always_inline)) {          // idx = half * RBW + rb
+            if (a.abl & 8) return;                  // ablation: multiply whatever the registers hold
             const int half = idx / RBW, rb = idx - half * RBW;
             const unsigned char* p = smem + st * STAGE + (fbase ^ (half * 64)) + rb * 2048;
 #pragma unroll
@@ -245,6 +250,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         // of a block's three reads behind the 4th MFMA of the previous block and waits for them (lgkmcnt(0)) two MFMAs
         // later -- 32 cycles of cover for a ~100-cycle LDS round trip, at every row block
         AFrag f[3];
+        if (a.abl & 8) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) f[i].v[pl] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        }
         aload(f[0], 0);
         if (2 * RBW > 1) aload(f[1], 1);
 #pragma unroll
@@ -463,6 +474,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             epilogue(i_tile, i_m0, i_n0, true);
         }
     };
+    // diagnostic build: shader clock and 100 MHz reference clock at both ends of workgroup 0 -> the clock the chip actually
+    // held while this kernel ran (tools/pl2_timeline.py; the chip lowers it under matrix load, MI355X_MICROARCH.md 'DVFS')
+    if (DBG && a.dbg != nullptr && blockIdx.x == 0 && t == 0) {
+        a.dbg[500] = __builtin_amdgcn_s_memtime();
+        a.dbg[501] = __builtin_amdgcn_s_memrealtime();
+    }
     {
         BFrag bc, bn;
         bool have = next_in_tile();
@@ -479,9 +496,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         // one step per stage: publish stage `st`, start the loads of the following stage (possibly of the next tile),
         // multiply stage `st`, and run the epilogue when it was the last stage of its tile
         int dbg_n = 0;
-        const bool dbg = a.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
+        // stamps exist only in the diagnostic instantiation (DBG): even as untaken branches they sit between the barrier
+        // and the first MFMA of every stage, where nothing overlaps them (tools/mfma_rate.hip)
+        const bool dbg = DBG && a.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
         auto stamp = [&](int k) __attribute__((always_inline)) {
-            if (dbg && dbg_n < 40 && lane == 0) a.dbg[(wave ? 256 : 0) + dbg_n * 6 + k] = __builtin_amdgcn_s_memtime();
+            if constexpr (DBG) {
+                if (dbg && dbg_n < 40 && lane == 0) a.dbg[(wave ? 256 : 0) + dbg_n * 6 + k] = __builtin_amdgcn_s_memtime();
+            }
         };
         while (have) {
             stamp(0);
@@ -506,6 +527,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             ++dbg_n;
             have = more;
         }
+    }
+    if (DBG && a.dbg != nullptr && blockIdx.x == 0 && t == 0) {
+        a.dbg[502] = __builtin_amdgcn_s_memtime();
+        a.dbg[503] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -580,7 +605,10 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
         else return false;
     } else {
         if (rbw == 8) PL2_LAUNCH(8, 1);
-        else if (rbw == 9) PL2_LAUNCH(9, 1);
+        else if (rbw == 9 && a.dbg != nullptr) {          // iswm_set_debug_buffer: the stamped instantiation
+            if (dgrad) hipLaunchKernelGGL((k_conv_pl2<9, 1, 3, true, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((k_conv_pl2<9, 1, 3, false, true>), grid, blk, 0, s, a);
+        } else if (rbw == 9) PL2_LAUNCH(9, 1);
         else if (rbw == 10) PL2_LAUNCH(10, 1);
         else return false;
     }

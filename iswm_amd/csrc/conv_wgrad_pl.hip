@@ -450,6 +450,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
 #undef ISWM_SB
     };
 
+    if (a.dbg != nullptr && blockIdx.x == 0 && t == 0) {          // in-kernel clock (tools/wgrad_timeline.py)
+        a.dbg[500] = __builtin_amdgcn_s_memtime();
+        a.dbg[501] = __builtin_amdgcn_s_memrealtime();
+    }
     {
         int dbg_n = 0;
         const bool dbg = a.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
@@ -476,6 +480,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
             ++dbg_n;
         }
         stamp(0);
+    }
+    if (a.dbg != nullptr && blockIdx.x == 0 && t == 0) {
+        a.dbg[502] = __builtin_amdgcn_s_memtime();
+        a.dbg[503] = __builtin_amdgcn_s_memrealtime();
     }
 
     if (a.nsplit > 1) {

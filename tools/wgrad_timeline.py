@@ -10,7 +10,7 @@ cin, cout, k, pad, dil = a
 xh = ops.split_planes(torch.randn(16, 33, 33, cin, device=dev))
 dyh = ops.split_planes(torch.randn(16, 33, 33, cout, device=dev))
 g = ops.ConvGeom(xh, cout, k, k, 1, pad, dil)
-for _ in range(3):
+for _ in range(int(os.environ.get("WG_WARM_LAUNCHES", "20000"))):      # >= 2 s of load: the clock the chip settles on is part of the answer
     ops.conv2d_wgrad(xh, dyh, g)
 buf = torch.zeros(512, dtype=torch.int64, device=dev)
 lib = _lib.load()
@@ -19,6 +19,9 @@ ops.conv2d_wgrad(xh, dyh, g)
 torch.cuda.synchronize()
 lib.iswm_set_debug_buffer(None)
 b = buf.cpu().tolist()
+if b[503] > b[501]:
+    cyc, ref = b[502] - b[500], b[503] - b[501]
+    print("workgroup 0: %d shader cycles in %.2f us -> %.2f GHz in-kernel clock" % (cyc, ref / 100.0, cyc / (ref / 100.0) / 1e3))
 names = ["wait vmcnt", "barrier", "next+issue", "multiply"]
 for wv, base in ((0, 0), (4, 256)):
     print("wave %d: step | %s | to next step" % (wv, " | ".join(names)))
