@@ -49,7 +49,7 @@ unsigned long long* g_conv_dbg = nullptr;        // iswm_set_debug_buffer
 // Tile = (16 * RBW * WM) rows x (128 / WM) columns; wave (wm, wn) owns rows [wm*16*RBW, +16*RBW) and columns 16*wn..+15.
 // PERSISTENT: the grid is min(tiles, CUs) workgroups; a workgroup walks tiles  it * gridDim + xcd_remap(blockIdx)  and its
 // stage pipeline runs across tile boundaries, so a tile's epilogue overlaps the DMA of the next tile's first stage.
-template <int RBW, int WM, int NP, bool DGRAD, bool DBG = false>
+template <int RBW, int WM, int NP, bool DGRAD, bool DBG = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
     const int GC = DGRAD ? a.Cout : a.Cin;     // channels of the gathered operand (per tap)
     const int NC = DGRAD ? a.Cin : a.Cout;     // output columns
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         // fragments of row block i+1 are read while block i is multiplied; the scheduling fences keep hipcc from
         // hoisting all 2 * RBW * NP fragment reads of a stage to its top (216 VGPRs for RBW = 9)
         auto aload = [&](AFrag& f, int idx) __attribute__((always_inline)) {          // idx = half * RBW + rb
-            if (a.abl & 8) return;                  // ablation: multiply whatever the registers hold
+            if (ABL & 8) return;                    // ablation: multiply whatever the registers hold
             const int half = idx / RBW, rb = idx - half * RBW;
             const unsigned char* p = smem + st * STAGE + (fbase ^ (half * 64)) + rb * 2048;
 #pragma unroll
@@ -237,20 +237,34 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         // spread evenly over the row blocks (front-loading them -- two per block over the first half of the stage -- measured
         // 8-12 % slower: the issue burst is what hurts)
         constexpr int PER = (NSLOTS + 2 * RBW - 1) / (2 * RBW);          // load slots per row block
+        // The following stage's loads are issued unconditionally -- a scalar branch per row block costs more than the load it
+        // would skip once per tile stream (tools/mfma_rate.hip): after the last stage they re-read the current weight block
+        // and DMA the zero row into the idle stage buffer (drained by the s_waitcnt at the end of the kernel).
         const uint4* wn_ = wpk + (size_t)k32n * (64 * NP);
+        const unsigned char* asrc[NRG];
+        long long apl[NRG];
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) {
+            asrc[i] = more ? aptr[i] : zrow;
+            apl[i] = more ? pst[i] : 0;
+        }
         auto slot = [&](int sidx) __attribute__((always_inline)) {
             if (sidx < NB_SLOTS) {
-                if (!(a.abl & 1)) bn.v[sidx / NP][sidx % NP] = wn_[sidx * 64];
+                if (!(ABL & 1)) bn.v[sidx / NP][sidx % NP] = wn_[sidx * 64];
             } else if (sidx < NSLOTS) {
                 const int i = (sidx - NB_SLOTS) / NP, pp = (sidx - NB_SLOTS) % NP;
-                if (wave + 8 * i < RG && !(a.abl & 2)) glds16b(aptr[i] + pp * pst[i], lds_base + (st ^ 1) * STAGE + pp * PLANE + (wave + 8 * i) * 1024);
+                if (!(ABL & 2)) {
+                    if (8 * i + 8 <= RG || wave + 8 * i < RG)
+                        glds16b(asrc[i] + pp * apl[i], lds_base + (st ^ 1) * STAGE + pp * PLANE + (wave + 8 * i) * 1024);
+                }
+                if (pp == NP - 1) aptr[i] += astep[i];          // this row group's pointer moves on to the stage after
             }
         };
         // fragments are read TWO row blocks ahead of their multiply, with the order pinned: left to itself hipcc sinks two
         // of a block's three reads behind the 4th MFMA of the previous block and waits for them (lgkmcnt(0)) two MFMAs
         // later -- 32 cycles of cover for a ~100-cycle LDS round trip, at every row block
         AFrag f[3];
-        if (a.abl & 8) {
+        if (ABL & 8) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -263,15 +277,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             if (idx + 2 < 2 * RBW) aload(f[(idx + 2) % 3], idx + 2);
             __builtin_amdgcn_sched_barrier(0);
             mul(f[idx % 3], idx);
-            if (more) {
 #pragma unroll
-                for (int q = 0; q < PER; ++q) slot(idx * PER + q);
-            }
+            for (int q = 0; q < PER; ++q) slot(idx * PER + q);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < NRG; ++i) aptr[i] += astep[i];
         }
     };
 
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             stamp(0);
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's DMA pieces and weight fragments landed
             stamp(1);
-            if (!(a.abl & 4)) __builtin_amdgcn_s_barrier();                // ... everyone's did; the other stage buffer is free
+            if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                // ... everyone's did; the other stage buffer is free
             asm volatile("" ::: "memory");
             stamp(2);
             bool more = next_in_tile();
@@ -528,6 +536,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
             have = more;
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the idle loads of the last stage
     if (DBG && a.dbg != nullptr && blockIdx.x == 0 && t == 0) {
         a.dbg[502] = __builtin_amdgcn_s_memtime();
         a.dbg[503] = __builtin_amdgcn_s_memrealtime();
@@ -605,7 +614,20 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
         else return false;
     } else {
         if (rbw == 8) PL2_LAUNCH(8, 1);
-        else if (rbw == 9 && a.dbg != nullptr) {          // iswm_set_debug_buffer: the stamped instantiation
+        else if (rbw == 9 && a.abl != 0) {               // ISWM_PL2_ABL: timing ablations are compile-time variants
+#define PL2_ABL_LAUNCH(A)                                                                                        \
+    do {                                                                                                         \
+        if (dgrad) hipLaunchKernelGGL((k_conv_pl2<9, 1, 3, true, false, A>), grid, blk, 0, s, a);                 \
+        else hipLaunchKernelGGL((k_conv_pl2<9, 1, 3, false, false, A>), grid, blk, 0, s, a);                      \
+    } while (0)
+            if (a.abl == 1) PL2_ABL_LAUNCH(1);
+            else if (a.abl == 2) PL2_ABL_LAUNCH(2);
+            else if (a.abl == 3) PL2_ABL_LAUNCH(3);
+            else if (a.abl == 7) PL2_ABL_LAUNCH(7);
+            else if (a.abl == 15) PL2_ABL_LAUNCH(15);
+            else return false;
+#undef PL2_ABL_LAUNCH
+        } else if (rbw == 9 && a.dbg != nullptr) {          // iswm_set_debug_buffer: the stamped instantiation
             if (dgrad) hipLaunchKernelGGL((k_conv_pl2<9, 1, 3, true, true>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((k_conv_pl2<9, 1, 3, false, true>), grid, blk, 0, s, a);
         } else if (rbw == 9) PL2_LAUNCH(9, 1);
