@@ -269,7 +269,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pl(const WgArgs a) {
 // and fetches 72 KB for it (23 B/clk at full matrix rate instead of 31; a single workgroup per CU is fed ~30 B/clk,
 // profiles/r02_ta_bw.txt).  Eight waves as 2 x 4, each a 64 x 64 block over the whole step: no k-half split, so no LDS
 // combine at the end.  Two stage buffers of [A | B0 | B1] images (144 KB).
-template <int NP>
+// DBG: per-step stamps and the in-kernel clock (tools/wgrad_timeline.py); ABL: timing ablations (1 no DMA, 2 no multiply).
+// Both are compile-time: an untaken scalar branch between the barrier and the first MFMA of a step is not free
+// (tools/mfma_rate.hip), and the production instantiation carries none of them.
+template <int NP, bool DBG = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
     constexpr int PLANE = 32 * 256;            // bytes of one plane of one 128-channel image of one stage
     constexpr int IMG = NP * PLANE;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
         else glds16w(bsrc[img - 1] + pl * bpst[img - 1], dst);
     };
     auto issue = [&](int st) __attribute__((always_inline)) {
-        if (a.abl & 1) return;
+        if (ABL & 1) return;
 #pragma unroll
         for (int i = 0; i < 3 * NP; ++i) dma(i, st);
     };
@@ -450,15 +453,17 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
 #undef ISWM_SB
     };
 
-    if (a.dbg != nullptr && blockIdx.x == 0 && t == 0) {          // in-kernel clock (tools/wgrad_timeline.py)
+    if (DBG && a.dbg != nullptr && blockIdx.x == 0 && t == 0) {          // in-kernel clock
         a.dbg[500] = __builtin_amdgcn_s_memtime();
         a.dbg[501] = __builtin_amdgcn_s_memrealtime();
     }
     {
         int dbg_n = 0;
-        const bool dbg = a.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
+        const bool dbg = DBG && a.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
         auto stamp = [&](int k) __attribute__((always_inline)) {
-            if (dbg && dbg_n < 40 && lane == 0) a.dbg[(wave ? 256 : 0) + dbg_n * 6 + k] = __builtin_amdgcn_s_memtime();
+            if constexpr (DBG) {
+                if (dbg && dbg_n < 40 && lane == 0) a.dbg[(wave ? 256 : 0) + dbg_n * 6 + k] = __builtin_amdgcn_s_memtime();
+            }
         };
         bool have = next();
         if (have) issue(0);
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
             const bool more = next();
             if (more) issue(st ^ 1);
             stamp(3);
-            if (!(a.abl & 2)) compute(st);
+            if (!(ABL & 2)) compute(st);
             stamp(4);
             st ^= 1;
             have = more;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
         }
         stamp(0);
     }
-    if (a.dbg != nullptr && blockIdx.x == 0 && t == 0) {
+    if (DBG && a.dbg != nullptr && blockIdx.x == 0 && t == 0) {
         a.dbg[502] = __builtin_amdgcn_s_memtime();
         a.dbg[503] = __builtin_amdgcn_s_memrealtime();
     }
@@ -608,6 +613,10 @@ void launch_wgrad_pl(const WgArgs& a, int planes, int wide, hipStream_t s) {
     dim3 grid(a.MT * a.NT * a.nsplit), blk(512);
     if (wide) {
         if (planes == 1) hipLaunchKernelGGL(k_wgrad_plw<1>, grid, blk, 0, s, a);
+        else if (a.abl == 1) hipLaunchKernelGGL((k_wgrad_plw<3, false, 1>), grid, blk, 0, s, a);
+        else if (a.abl == 2) hipLaunchKernelGGL((k_wgrad_plw<3, false, 2>), grid, blk, 0, s, a);
+        else if (a.abl == 3) hipLaunchKernelGGL((k_wgrad_plw<3, false, 3>), grid, blk, 0, s, a);
+        else if (a.dbg != nullptr) hipLaunchKernelGGL((k_wgrad_plw<3, true, 0>), grid, blk, 0, s, a);
         else hipLaunchKernelGGL(k_wgrad_plw<3>, grid, blk, 0, s, a);
     } else {
         if (planes == 1) hipLaunchKernelGGL(k_wgrad_pl<1>, grid, blk, 0, s, a);
