@@ -15,6 +15,9 @@ python3 tools/pmc_aggregate.py $out/pmc/f/f_counter_collection.csv $out/pmc/w/w_
 python3 tools/pl_check.py 20 > $out/pl_check.txt 2>&1
 python3 tools/pl2_timeline.py > $out/pl2_timeline.txt 2>&1
 python3 tools/ew_bench.py > $out/elementwise.txt 2>&1
+python3 tools/wgrad_timeline.py 256 256 3 1 1 > $out/wgrad_timeline.txt 2>&1
+python3 tools/pl2_ab.py 30 > $out/pl2_stamps_ab.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 tools/mfma_rate.hip -o /tmp/mfma_rate > /dev/null 2>&1 && timeout -k 5 200 /tmp/mfma_rate > $out/mfma_rate.txt 2>&1
 for k in "pl2 1024 256 1 0 1" "pl2 256 256 3 1 1" "wgrad 1024 256 1 0 1" "wgrad 256 256 3 1 1"; do
   set -- $k; kind=$1; shift
   name=$(echo $kind $* | tr ' ' '_')
