@@ -818,15 +818,15 @@ namespace iswm { int wgrad_pl_is_wide(const iswm_conv_desc* d); }
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
     ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 7, "kernel_name: bad argument");
     if (kind == 7) {   // iswm_conv2d_wgrad_planes
-        snprintf(buf, buflen, wgrad_pl_is_wide(d) ? "k_wgrad_plw<%d>" : "k_wgrad_pl<%d>", math_planes());
+        snprintf(buf, buflen, wgrad_pl_is_wide(d) ? "k_wgrad_plw<%d, false, 0>" : "k_wgrad_pl<%d>", math_planes());
         return 0;
     }
     if (kind >= 5) {   // 5 / 6: iswm_conv2d_fwd_pl2 / iswm_conv2d_dgrad_pl2
         const bool dg = kind == 6;
         const int cols = dg ? d->Cin : d->Cout;
         const int rbw = conv_pl2_pick_rbw(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, cols);
-        if (cols <= 64) snprintf(buf, buflen, "k_conv_pl2<%d, 2, %d, %s>", rbw / 2, math_planes(), dg ? "true" : "false");
-        else snprintf(buf, buflen, "k_conv_pl2<%d, 1, %d, %s>", rbw, math_planes(), dg ? "true" : "false");
+        if (cols <= 64) snprintf(buf, buflen, "k_conv_pl2<%d, 2, %d, %s, false, 0>", rbw / 2, math_planes(), dg ? "true" : "false");
+        else snprintf(buf, buflen, "k_conv_pl2<%d, 1, %d, %s, false, 0>", rbw, math_planes(), dg ? "true" : "false");
         return 0;
     }
     if (kind >= 3) {   // 3 / 4: iswm_conv2d_fwd_packed / iswm_conv2d_dgrad_packed
