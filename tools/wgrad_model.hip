@@ -24,14 +24,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // RD: 0 no LDS reads, 1 transposing reads one block ahead
 // SMALL: 1 -> v_mfma_f32_16x16x32_bf16 (twice as many, same FLOPs)
 template <int DMA, int RD, int SMALL, int BK = 0>
-__global__ __launch_bounds__(512, 2) void k(unsigned long long* out, float* sink, const unsigned char* src, int steps) {
+__global__ __launch_bounds__(512, 2) void k(unsigned long long* out, float* sink, const unsigned char* src, int steps, long long wg_stride, long long step_stride) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 73728];
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_vptr)smem;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     for (int i = t; i < 2 * 73728 / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0x3c003c00u + i, 0x3d003d00u, 0x3c803c80u, 0x3d803d80u);
     __syncthreads();
-    const unsigned char* gp = src + (size_t)blockIdx.x * 73728 + (size_t)lane * 16 + (size_t)wave * 1024;
+    const unsigned char* gp0 = src + (size_t)blockIdx.x * wg_stride + (size_t)lane * 16 + (size_t)wave * 1024;
+    const unsigned char* gp = gp0;
     f32x16 acc[4];
     f32x4 acs[16];
     for (int i = 0; i < 4; ++i)
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, float* sink
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        gp = gp0 + (size_t)((s + 1) % steps) * step_stride;      // the step after next streams from here
         if (BK == 1) next();
         if (DMA == 1) {
 #pragma unroll
@@ -157,14 +159,14 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, float* sink
 }
 
 template <int DMA, int RD, int SMALL, int BK = 0>
-static void run(const char* what, unsigned long long* d_out, float* d_sink, const unsigned char* d_src) {
+static void run(const char* what, unsigned long long* d_out, float* d_sink, const unsigned char* d_src, long long wg_stride = 73728, long long step_stride = 0) {
     const int steps = 400;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL((k<DMA, RD, SMALL, BK>), dim3(256), dim3(512), 0, 0, d_out, d_sink, d_src, steps);
+    for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL((k<DMA, RD, SMALL, BK>), dim3(256), dim3(512), 0, 0, d_out, d_sink, d_src, steps, wg_stride, step_stride);
     hipEventRecord(e0, 0);
-    for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL((k<DMA, RD, SMALL, BK>), dim3(256), dim3(512), 0, 0, d_out, d_sink, d_src, steps);
+    for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL((k<DMA, RD, SMALL, BK>), dim3(256), dim3(512), 0, 0, d_out, d_sink, d_src, steps, wg_stride, step_stride);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0.f;
@@ -181,7 +183,7 @@ int main() {
     unsigned long long* d_out;
     float* d_sink;
     unsigned char* d_src;
-    const size_t nsrc = (size_t)256 * 73728 + 65536;
+    const size_t nsrc = (size_t)256 * 400 * 73728 + 65536;      // 7.5 GB: every step of every workgroup its own 72 KB
     if (hipMalloc(&d_out, 64) != hipSuccess || hipMalloc(&d_sink, 4096) != hipSuccess || hipMalloc(&d_src, nsrc) != hipSuccess) return 1;
     hipMemset(d_src, 0x3c, nsrc);
     run<0, 0, 0>("MFMA + barrier only", d_out, d_sink, d_src);
@@ -193,6 +195,9 @@ int main() {
     run<1, 1, 0, 1>("kernel's step + address bookkeeping after the barrier", d_out, d_sink, d_src);
     run<1, 1, 0, 2>("kernel's step + address bookkeeping inside the last blocks", d_out, d_sink, d_src);
     run<2, 1, 0, 2>("DMA dealt + address bookkeeping inside the last blocks", d_out, d_sink, d_src);
+    run<1, 1, 0>("kernel's step, operands streamed from a 470-MB footprint (8 steps per workgroup wrap)", d_out, d_sink, d_src, 8LL * 73728 * 25, 73728LL * 25 / 25);
+    run<1, 1, 0>("kernel's step, every step its own 72 KB of a 7.5-GB buffer (HBM)", d_out, d_sink, d_src, 400LL * 73728, 73728);
+    run<2, 1, 0>("DMA dealt, every step its own 72 KB (HBM)", d_out, d_sink, d_src, 400LL * 73728, 73728);
     run<0, 0, 1>("16x16x32: MFMA + barrier only", d_out, d_sink, d_src);
     run<1, 1, 1>("16x16x32: DMA burst + LDS reads", d_out, d_sink, d_src);
     run<2, 1, 1>("16x16x32: DMA dealt + LDS reads", d_out, d_sink, d_src);
