@@ -80,9 +80,18 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     __shared__ double mean_s[CPB];
     const int cl = threadIdx.x % CPB, tl = threadIdx.x / CPB;
     const int c = blockIdx.x * CPB + cl;
+    // (these kernels are pure latency: a handful of dependent L2 round trips between two launches.  Four loads in flight
+    // per thread and 64 tile lanes per channel keep the chain to 1-2 round trips per pass for the usual 121-242 tiles)
     double s = 0.0;
-    if (c < C)
-        for (int k = tl; k < tiles; k += TL) s += (double)partials[(size_t)k * C + c];
+    if (c < C) {
+        int k = tl;
+        for (; k + 3 * TL < tiles; k += 4 * TL) {
+            const float v0 = partials[(size_t)k * C + c], v1 = partials[(size_t)(k + TL) * C + c];
+            const float v2 = partials[(size_t)(k + 2 * TL) * C + c], v3 = partials[(size_t)(k + 3 * TL) * C + c];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; k < tiles; k += TL) s += (double)partials[(size_t)k * C + c];
+    }
     red[tl][cl] = s;
     __syncthreads();
     if (tl == 0) {
@@ -92,12 +101,20 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     __syncthreads();
     const double mean = mean_s[cl];
     double m2 = 0.0;
-    if (c < C)
-        for (int k = tl; k < tiles; k += TL) {
-            double nt = R > 0.0 ? fmin(R, count - (double)k * R) : (double)partials[(size_t)2 * tiles * C + k];
-            double d = (double)partials[(size_t)k * C + c] / nt - mean;
-            m2 += (double)partials[(size_t)(tiles + k) * C + c] + nt * d * d;
+    if (c < C) {
+        auto term = [&](int k, float sk, float qk) -> double {
+            const double nt = R > 0.0 ? fmin(R, count - (double)k * R) : (double)partials[(size_t)2 * tiles * C + k];
+            const double d = (double)sk / nt - mean;
+            return (double)qk + nt * d * d;
+        };
+        int k = tl;
+        for (; k + TL < tiles; k += 2 * TL) {
+            const float s0 = partials[(size_t)k * C + c], s1 = partials[(size_t)(k + TL) * C + c];
+            const float q0 = partials[(size_t)(tiles + k) * C + c], q1 = partials[(size_t)(tiles + k + TL) * C + c];
+            m2 += term(k, s0, q0) + term(k + TL, s1, q1);
         }
+        for (; k < tiles; k += TL) m2 += term(k, partials[(size_t)k * C + c], partials[(size_t)(tiles + k) * C + c]);
+    }
     __syncthreads();
     red[tl][cl] = m2;
     __syncthreads();
@@ -326,11 +343,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const T* __restrict__ p
     const int cl = threadIdx.x % CPB, tl = threadIdx.x / CPB;
     const int c = blockIdx.x * CPB + cl;
     double s = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int k = tl; k < tiles; k += TL) {
+    if (c < C) {
+        int k = tl;
+        for (; k + TL < tiles; k += 2 * TL) {          // four loads in flight per thread
+            const T a0 = partials[(size_t)k * C + c], a1 = partials[(size_t)(k + TL) * C + c];
+            const T b0 = partials[(size_t)(tiles + k) * C + c], b1 = partials[(size_t)(tiles + k + TL) * C + c];
+            s += (double)a0 + (double)a1;
+            s2 += (double)b0 + (double)b1;
+        }
+        for (; k < tiles; k += TL) {
             s += (double)partials[(size_t)k * C + c];
             s2 += (double)partials[(size_t)(tiles + k) * C + c];
         }
+    }
     red[0][tl][cl] = s;
     red[1][tl][cl] = s2;
     __syncthreads();
@@ -458,7 +483,7 @@ extern "C" int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t
                      tile_rows >= 0 && (tile_rows == 0 || (int64_t)tiles == (count + tile_rows - 1) / tile_rows),
                  "bn_finalize: bad argument (tiles %d, count %lld, tile_rows %lld)", tiles, (long long)count,
                  (long long)tile_rows);
-    if (tiles > 128)
+    if (tiles > 32)
         hipLaunchKernelGGL((k_bn_finalize<4>), dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
                            (double)count, (double)tile_rows, gamma, beta, running_mean, running_var, momentum, eps,
                            scale, shift, save_mean, save_invstd);
@@ -595,7 +620,7 @@ static int bn_backward_impl(const float* dout, int ldd, const void* out, int ldo
 #undef RLAUNCH
         if (int e = check_launch("bn_bwd_reduce")) return e;
     }
-    if (tiles > 128)
+    if (tiles > 32)
         hipLaunchKernelGGL((k_bn_bwd_finalize<double, 4>), dim3((C + 3) / 4), dim3(256), 0, s, partials, tiles, C,
                            dgamma, dbeta, sums);
     else
