@@ -80,17 +80,22 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     __shared__ double mean_s[CPB];
     const int cl = threadIdx.x % CPB, tl = threadIdx.x / CPB;
     const int c = blockIdx.x * CPB + cl;
-    // (these kernels are pure latency: a handful of dependent L2 round trips between two launches.  Four loads in flight
-    // per thread and 64 tile lanes per channel keep the chain to 1-2 round trips per pass for the usual 121-242 tiles)
+    // (these kernels are pure latency: a few dependent L2 round trips between two launches.  Both partials of up to
+    // KEEP tiles per thread are loaded ONCE, all in flight together, and the second pass runs out of registers: one round
+    // trip for the usual 121-242 tiles at 64 tile lanes per channel, and for the 1849 tiles of a 129 x 129 map at 256)
+    constexpr int KEEP = 8;
+    float sv[KEEP], qv[KEEP];
     double s = 0.0;
     if (c < C) {
-        int k = tl;
-        for (; k + 3 * TL < tiles; k += 4 * TL) {
-            const float v0 = partials[(size_t)k * C + c], v1 = partials[(size_t)(k + TL) * C + c];
-            const float v2 = partials[(size_t)(k + 2 * TL) * C + c], v3 = partials[(size_t)(k + 3 * TL) * C + c];
-            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int k = tl + i * TL;
+            sv[i] = k < tiles ? partials[(size_t)k * C + c] : 0.f;
+            qv[i] = k < tiles ? partials[(size_t)(tiles + k) * C + c] : 0.f;
         }
-        for (; k < tiles; k += TL) s += (double)partials[(size_t)k * C + c];
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) s += (double)sv[i];
+        for (int k = tl + KEEP * TL; k < tiles; k += TL) s += (double)partials[(size_t)k * C + c];
     }
     red[tl][cl] = s;
     __syncthreads();
@@ -107,13 +112,12 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
             const double d = (double)sk / nt - mean;
             return (double)qk + nt * d * d;
         };
-        int k = tl;
-        for (; k + TL < tiles; k += 2 * TL) {
-            const float s0 = partials[(size_t)k * C + c], s1 = partials[(size_t)(k + TL) * C + c];
-            const float q0 = partials[(size_t)(tiles + k) * C + c], q1 = partials[(size_t)(tiles + k + TL) * C + c];
-            m2 += term(k, s0, q0) + term(k + TL, s1, q1);
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int k = tl + i * TL;
+            if (k < tiles) m2 += term(k, sv[i], qv[i]);
         }
-        for (; k < tiles; k += TL) m2 += term(k, partials[(size_t)k * C + c], partials[(size_t)(tiles + k) * C + c]);
+        for (int k = tl + KEEP * TL; k < tiles; k += TL) m2 += term(k, partials[(size_t)k * C + c], partials[(size_t)(tiles + k) * C + c]);
     }
     __syncthreads();
     red[tl][cl] = m2;
@@ -483,7 +487,11 @@ extern "C" int iswm_bn_finalize(const float* partials, int tiles, int C, int64_t
                      tile_rows >= 0 && (tile_rows == 0 || (int64_t)tiles == (count + tile_rows - 1) / tile_rows),
                  "bn_finalize: bad argument (tiles %d, count %lld, tile_rows %lld)", tiles, (long long)count,
                  (long long)tile_rows);
-    if (tiles > 32)
+    if (tiles > 512)
+        hipLaunchKernelGGL((k_bn_finalize<1>), dim3(C), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
+                           (double)count, (double)tile_rows, gamma, beta, running_mean, running_var, momentum, eps,
+                           scale, shift, save_mean, save_invstd);
+    else if (tiles > 32)
         hipLaunchKernelGGL((k_bn_finalize<4>), dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
                            (double)count, (double)tile_rows, gamma, beta, running_mean, running_var, momentum, eps,
                            scale, shift, save_mean, save_invstd);
