@@ -666,9 +666,25 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restric
                                int nsplit) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        float4 s = reinterpret_cast<const float4*>(slabs)[i];
-        for (int k = 1; k < nsplit; ++k) {
-            float4 v = reinterpret_cast<const float4*>(slabs)[i + (int64_t)k * n4];
+        // a small weight (a 1x1 on a large map: 4 096 float4, 64-128 splits) leaves each thread a long chain of dependent
+        // round trips: eight loads in flight per thread, summed in the fixed order 1, 2, 3, ...
+        const float4* p = reinterpret_cast<const float4*>(slabs) + i;
+        float4 s = p[0];
+        int k = 1;
+        for (; k + 7 < nsplit; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * n4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s.x += v[u].x;
+                s.y += v[u].y;
+                s.z += v[u].z;
+                s.w += v[u].w;
+            }
+        }
+        for (; k < nsplit; ++k) {
+            const float4 v = p[(int64_t)k * n4];
             s.x += v.x;
             s.y += v.y;
             s.z += v.z;
