@@ -27,7 +27,7 @@ inline RowPlan plan_rows(int64_t M, int C, int fixed_rowblocks = 0) {
         p.rowblocks = fixed_rowblocks;
     } else {
         int64_t rb = (M + (int64_t)p.RL * 4 - 1) / ((int64_t)p.RL * 4);
-        int64_t cap = 2048 / p.colblocks;
+        int64_t cap = 8192 / p.colblocks;
         if (cap < 1) cap = 1;
         if (rb > cap) rb = cap;
         if (rb < 1) rb = 1;
