@@ -243,7 +243,7 @@ def main():
     net = model
     if world > 1:
         group = dist.group.WORLD
-        net = DistributedDataParallelHIP(model, process_group=group)
+        net = DistributedDataParallelHIP(model, process_group=group, time_waits=True)
         net.attach(opt)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=30000, eta_min=0.01 * 0.01)   # train.py:446-452
     crit = CrossEntropyLoss(weight=torch.tensor([1.0, 3.0]), ignore_index=255, group=group).to(dev)

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
 int conv_pl2_pick_rbw(int64_t M, int cols) {
     if (const char* e = getenv("ISWM_PL2_RBW")) {
         const int v = atoi(e);
-        if (v >= 8 && v <= PL2_RBWMAX) return v;
+        if (v >= 8 && v <= PL2_RBWMAX && !(cols <= 64 && v == 9)) return v;      // 64-column tiles have no 9-block form
     }
     const int64_t NT = cols <= 64 ? 1 : (cols + 127) / 128;
     int best = PL2_RBWMAX;

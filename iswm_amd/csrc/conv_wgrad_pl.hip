@@ -632,23 +632,31 @@ namespace iswm {
 void launch_reduce_slabs(const float* slabs, float* dst, int64_t n4, int nsplit, hipStream_t s);
 }
 
-static int wg_validate(const iswm_conv_desc* d) {
-    ISWM_REQUIRE(d != nullptr, "wgrad_planes: null descriptor");
-    ISWM_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "wgrad_planes: empty tensor");
-    ISWM_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout,
-                 "wgrad_planes: channel counts and pitches must be multiples of 8 (Cin %d Cout %d ldx %d ldy %d)", d->Cin,
-                 d->Cout, d->ldx, d->ldy);
-    ISWM_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "wgrad_planes: bad geometry");
+// every precondition of the planes weight gradient in ONE place: iswm_conv2d_wgrad_planes_ok() answers with it (callers
+// fall back to the fp32-input weight gradient) and the entry point refuses with its message.  nullptr = acceptable.
+static const char* wg_refusal(const iswm_conv_desc* d) {
+    if (d == nullptr) return "wgrad_planes: null descriptor";
+    if (!(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0)) return "wgrad_planes: empty tensor";
+    if (!(d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout))
+        return "wgrad_planes: channel counts and pitches must be multiples of 8";
+    if (!(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0)) return "wgrad_planes: bad geometry";
     const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
-    ISWM_REQUIRE(ho == d->Ho && wo == d->Wo, "wgrad_planes: output size does not match geometry");
-    ISWM_REQUIRE((int64_t)d->N * d->H * d->W * d->ldx < (1ll << 30) && (int64_t)d->N * d->Ho * d->Wo * d->ldy < (1ll << 30),
-                 "wgrad_planes: tensor too large");
+    if (!(ho == d->Ho && wo == d->Wo)) return "wgrad_planes: output size does not match geometry";
+    if (!((int64_t)d->N * d->H * d->W * d->ldx < (1ll << 30) && (int64_t)d->N * d->Ho * d->Wo * d->ldy < (1ll << 30)))
+        return "wgrad_planes: tensor too large (2^30 elements per operand)";
+    return nullptr;
+}
+
+static int wg_validate(const iswm_conv_desc* d) {
+    const char* why = wg_refusal(d);
+    ISWM_REQUIRE(why == nullptr, "%s (Cin %d Cout %d ldx %d ldy %d)", why, d ? d->Cin : 0, d ? d->Cout : 0, d ? d->ldx : 0,
+                 d ? d->ldy : 0);
     return 0;
 }
 
 extern "C" int iswm_conv2d_wgrad_planes_ok(const iswm_conv_desc* d) {
-    return (d && d->Cin % 8 == 0 && d->Cout % 8 == 0 && iswm_get_conv_math() >= 1) ? 1 : 0;
+    return (wg_refusal(d) == nullptr && iswm_get_conv_math() >= 1) ? 1 : 0;
 }
 
 extern "C" size_t iswm_conv2d_wgrad_planes_workspace(const iswm_conv_desc* d) {

@@ -427,14 +427,23 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=Non
     return dx
 
 
+def _wgrad_planes_ok(x, dy, g, c8):
+    """iswm_conv2d_wgrad_planes_ok on the descriptor the planes weight gradient would get (every precondition of the
+    kernel: channel / pitch alignment, the 2^30-element indexing bound); False -> the fp32-input weight gradient runs"""
+    ldx = pgeom(x)[4]
+    ldy = pgeom(dy)[4] if (isinstance(dy, Planes) and c8 == g.cout) else c8
+    d = ConvDesc(g.n, g.h, g.w, g.cin, g.ho, g.wo, c8, g.kh, g.kw, g.stride, g.pad, g.dil, ldx, ldy)
+    return bool(_lib.load().iswm_conv2d_wgrad_planes_ok(ctypes.byref(d)))
+
+
 def conv2d_wgrad(x, dy, g, dw_ohwi=None):
     """dw[Cout,KH,KW,Cin] = sum_pixels dy (x) gathered x.  With a pre-split x the planes kernel runs (dy is split
     here when the producer did not: the few-channel classifier gradient)."""
     if dw_ohwi is None:
         dw_ohwi = torch.empty((g.cout, g.kh, g.kw, g.cin), dtype=torch.float32, device=x.device)
     _check_w(dw_ohwi, g)
-    if isinstance(x, Planes) and planes_on() and g.cin % 8 == 0 and _WGRAD_PLANES:
-        c8 = (g.cout + 7) // 8 * 8
+    c8 = (g.cout + 7) // 8 * 8
+    if isinstance(x, Planes) and planes_on() and _WGRAD_PLANES and _wgrad_planes_ok(x, dy, g, c8):
         if not isinstance(dy, Planes) or c8 != g.cout:
             dyf = as_f32(dy)
             dy = new_planes(g.n, g.ho, g.wo, c8, x.device, zero=c8 != g.cout)

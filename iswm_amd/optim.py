@@ -196,27 +196,42 @@ class FusedAdam(_FusedBase):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         self._grads_ready()
+        segs = self._segments()
+        if not segs:
+            return loss             # nothing has a gradient: torch's Adam leaves every step counter alone too
         self._t += 1
         b1, b2 = g["betas"]
         self._push_hyper(g["lr"], 1.0 - b1 ** self._t, 1.0 - b2 ** self._t)
-        for a, b in self._segments():
+        for a, b in segs:
             ops.adam_step(self.arena.data[a:b], self.arena.grad[a:b], self._m[a:b], self._v[a:b], self._hyper_dev, b1, b2,
                           g["eps"], g["weight_decay"], g["decoupled"])
         ops.weights_changed()
         for p in self.arena.params:
-            self.state[p]["step"] += 1
+            if p.grad is not None:          # a frozen parameter's counter stays where it was (as in torch.optim.Adam)
+                self.state[p]["step"] += 1
         return loss
 
     def load_state_dict(self, state_dict):
+        """a stock torch.optim.Adam(W) checkpoint has NO state entry for a parameter that never received a gradient (a frozen
+        backbone): such parameters keep zero moments and a zero counter, and the arena views are reinstalled for all"""
         super().load_state_dict(state_dict)
+        t_max = 0
         for i, p in enumerate(self.arena.params):
+            st = self.state[p]
             for key, flat in (("exp_avg", self._m), ("exp_avg_sq", self._v)):
                 view = self.arena.view_of(flat, i)
-                t = self.state[p].get(key)
-                if t is not None and t.data_ptr() != view.data_ptr():
+                t = st.get(key)
+                if t is None:
+                    view.zero_()
+                elif t.data_ptr() != view.data_ptr():
                     view.copy_(t)
-                self.state[p][key] = view
-            self._t = int(self.state[p]["step"])
+                st[key] = view
+            step = st.get("step")
+            if step is None:
+                st["step"] = torch.tensor(0.0)
+            else:
+                t_max = max(t_max, int(step))
+        self._t = t_max             # one bias correction for the whole arena: the stepped parameters share a counter
 
 
 class FusedAdamW(FusedAdam):

@@ -29,8 +29,9 @@ from .optim import arena_of
 
 
 class DistributedDataParallelHIP(nn.Module):
-    def __init__(self, module, process_group=None, bucket_mb=32.0, broadcast=True):
+    def __init__(self, module, process_group=None, bucket_mb=32.0, broadcast=True, time_waits=False):
         super().__init__()
+        self.time_waits = bool(time_waits)       # bench.py: measure the exposed wait per step with ONE reusable event pair
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -67,7 +68,7 @@ class DistributedDataParallelHIP(nn.Module):
         self._sync = True
         # diagnostics for bench.py: what was all-reduced and how long the compute stream stood still for it
         self.stats = dict(bytes_allreduced=0, allreduces=0, steps=0, exposed_wait_ms=0.0)
-        self._wait_events = []
+        self._wait_pair = None      # (start, end) events of the previous step's wait, folded into stats at the next one
         module._iswm_on_ready = self._on_ready
 
     def forward(self, *args, **kwargs):
@@ -99,26 +100,42 @@ class DistributedDataParallelHIP(nn.Module):
     def finish_grad_sync(self):
         """Block the compute stream until every bucket's all-reduce has landed (call before
         optimizer.step(); ``attach`` does it automatically)."""
-        timed = bool(self._works) and self.arena.grad.is_cuda
+        if self.world > 1 and self._sync:
+            # torch's DDP raises when a bucket is left half-filled (a requires_grad parameter that got no gradient this
+            # step): its all-reduce would never be launched and the replicas would silently diverge
+            stuck = [b for b in range(len(self.buckets)) if 0 < self._left[b] < self._need[b]]
+            if stuck:
+                raise RuntimeError("DistributedDataParallelHIP: bucket(s) %s received only part of their gradients in this "
+                                   "backward pass (a parameter with requires_grad=True took no part in the loss); freeze it "
+                                   "with requires_grad_(False) before wrapping the model" % stuck)
+        timed = self.time_waits and bool(self._works) and self.arena.grad.is_cuda
         if timed:
-            a = torch.cuda.Event(enable_timing=True)
-            a.record()
+            self._fold_wait()
+            if self._wait_pair is None:
+                self._wait_pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), [False])
+            self._wait_pair[0].record()
         for w in self._works:
             w.wait()
         if timed:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
-            self._wait_events.append((a, b))
+            self._wait_pair[1].record()
+            self._wait_pair[2][0] = True
         if self._works:
             self.stats["steps"] += 1
         self._works = []
 
+    def _fold_wait(self):
+        """add the previous step's measured wait to the totals (the pair is re-recorded afterwards: nothing accumulates
+        in a long training run)"""
+        if self._wait_pair is not None and self._wait_pair[2][0]:
+            a, b, live = self._wait_pair
+            b.synchronize()
+            self.stats["exposed_wait_ms"] += a.elapsed_time(b)
+            live[0] = False
+
     def comm_stats(self):
         """totals since construction (call after a device synchronize): bytes and all-reduce launches, and the time the
         compute stream spent between reaching the optimizer step and the last bucket landing (exposed, not overlapped)"""
-        for a, b in self._wait_events:
-            self.stats["exposed_wait_ms"] += a.elapsed_time(b)
-        self._wait_events = []
+        self._fold_wait()
         out = dict(self.stats)
         out["buckets"] = len(self.buckets)
         out["backend"] = dist.get_backend(self.group) if dist.is_initialized() else "none"

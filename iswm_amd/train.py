@@ -290,7 +290,11 @@ def main(argv=None):
     model.train()
     interval_loss = torch.zeros((), device=device)
     t_last, n_last = time.time(), 0
-    cur_epochs = 0
+    # a resumed run continues the epoch count where it stopped (train.py:997): DistributedSampler.set_epoch would otherwise
+    # replay the shuffles the run already consumed
+    cur_epochs = cur_itrs // max(1, len(train_loader))
+    if rank == 0 and cur_itrs:
+        print("Resuming at iteration %d (epoch %d)" % (cur_itrs, cur_epochs))
     while cur_itrs < opts.total_itrs:
         cur_epochs += 1
         if sampler is not None:

@@ -234,6 +234,34 @@ def gen_loss(loss_mod, outdir):
 
 
 MODEL_CASES = [("r50_os16", "resnet50", 16), ("r101_os8", "resnet101", 8)]
+# input [N, H, W] per case.  r101 / os8 runs on 4 x 97 x 97 (13 x 13 maps: 676 values per BatchNorm channel): on 2 x 65 x 65
+# (9 x 9 maps, 162 values) train-mode BatchNorm through 100 layers is so ill-conditioned that the reference's own fp32
+# result sits 8.6e-4 from the float64 evaluation of the same graph -- no fp32 path can be held to 1e-3 against it.
+MODEL_INPUT = {"r50_os16": (2, 65, 65), "r101_os8": (4, 97, 97)}
+
+
+# r101 / os8 additionally damps the residual branches (every bn3.weight x 0.3, as in a trained or zero-init-residual
+# ResNet).  With the synthetic rule's gamma in [0.5, 1.5] on all 33 residual branches a rounding error grows ~1e4-fold
+# through the 100 train-mode BatchNorm layers, WHATEVER the map size: the reference's own fp32 logits sit 9.5e-4 (4 x 97 x 97)
+# and 8.6e-4 (2 x 65 x 65) from the float64 evaluation of the same graph; with the damping 3.9e-5.
+MODEL_BN3_DAMP = {"r50_os16": 1.0, "r101_os8": 0.3}
+
+
+def model_state(tag, cfg):
+    """the state_dict of a whole-model case (oracle.synth's per-key rule, plus the case's residual damping)"""
+    sd = synth_state_dict(cfg)
+    damp = MODEL_BN3_DAMP[tag]
+    if damp != 1.0:
+        for k in sd:
+            if k.endswith(".bn3.weight"):
+                sd[k] = sd[k] * damp
+    return sd
+
+
+def model_input(tag):
+    """(images, labels) of a whole-model case -- the tests rebuild them with the same seeded rule"""
+    n, h, w = MODEL_INPUT[tag]
+    return synth_images(n, h, w, seed=71), synth_labels(n, h, w, seed=71, p_fg=0.2, p_ignore=0.05)
 WATCH = ["backbone.conv1.weight", "backbone.layer1.0.conv2.weight", "backbone.layer4.2.conv2.weight",
          "classifier.aspp.convs.2.0.weight", "classifier.classifier.0.weight",
          "classifier.classifier.6.weight", "classifier.classifier.6.bias",
@@ -246,10 +274,9 @@ def gen_model(modeling, outdir):
         out = {}
         cfg = ArchCfg("deeplabv3plus", backbone, 2, os_)
         m = modeling._segm_resnet("deeplabv3plus", backbone, 2, os_, False)
-        m.load_state_dict(synth_state_dict(cfg), strict=True)
+        m.load_state_dict(model_state(tag, cfg), strict=True)
         m.classifier.aspp.project[3].p = 0.0
-        x = synth_images(2, 65, 65, seed=71)
-        labels = synth_labels(2, 65, 65, seed=71, p_fg=0.2, p_ignore=0.05)
+        x, labels = model_input(tag)
         out["labels"] = labels.numpy().astype(np.uint8)
         m.eval()
         with torch.no_grad():
@@ -400,6 +427,9 @@ def main():
     modeling, deeplab, resnet, loss = import_reference(args.ref)
     if args.only == "sepconv":
         gen_sepconv(deeplab, args.out)
+        return
+    if args.only == "model":
+        gen_model(modeling, args.out)
         return
     if args.only == "model_v3":
         gen_model_v3(modeling, args.out)

@@ -235,9 +235,12 @@ def test_whole_model(tag, backbone, os_):
     from oracle.deeplab import OracleDeepLab
     from oracle.make_golden import WATCH
     from oracle.synth import synth_images
+    from oracle.make_golden import model_input, model_state
     fx = load("model_%s.npz" % tag)
     m, cfg, sd = _build(backbone, os_)
-    x = synth_images(2, 65, 65, seed=71)
+    sd = model_state(tag, cfg)
+    m.load_state_dict(sd, strict=True)
+    x = model_input(tag)[0]
     labels = torch.from_numpy(fx["labels"].astype(np.int64))
     m.eval()
     with torch.no_grad():
@@ -252,14 +255,14 @@ def test_whole_model(tag, backbone, os_):
     m.train()
     with record_masks(m, "") as rec:
         lg = m(x.to(dev()))
-    # Train-mode BatchNorm over the 162 values per channel of the os8 case is ill-conditioned: the reference's own fp32
-    # result is 8.6e-4 away from the float64 evaluation of the same graph (tools/acc_check.py).  So every fp32
-    # evaluation is held to RTOL against FLOAT64, and two fp32 evaluations to the sum of their bounds.
+    # plain RTOL against the reference's own train-mode logits (the os8 case runs on 4 x 97 x 97 so that its BatchNorm
+    # layers see 676 values per channel: oracle/make_golden.py MODEL_INPUT) ...
+    assert rel_err(lg, fx["train_logits"]) <= RTOL
+    # ... and, as an extra, against the float64 evaluation of the same graph
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
         ref64 = OracleDeepLab(cfg, sd64, dropout_p=0.0).train()(x.double())
     assert rel_err(lg, ref64) <= RTOL
-    assert rel_err(lg, fx["train_logits"]) <= RTOL + rel_err(fx["train_logits"], ref64)
     w = torch.tensor([1.0, 3.0])
     loss = CrossEntropyLoss(weight=w, ignore_index=255)(lg, labels.to(dev()))
     assert rel_err(loss, fx["loss"]) <= RTOL
@@ -347,6 +350,51 @@ def test_train_steps_match_oracle():
     assert worst_b[0] <= RTOL, worst_b
     assert worst_u[0] <= 1e-2, worst_u
     assert int(msd["backbone.bn1.num_batches_tracked"]) == 3
+
+
+def test_full_size_step_vs_oracle():
+    """BASELINE.json configs[1] geometry (deeplabv3plus_resnet50, output_stride 16, 513 x 513) against the CPU oracle at
+    FULL size: eval logits, train logits and weighted-CE loss element-wise at 1e-3, and every parameter gradient
+    element-wise at 3e-3 with the oracle's ReLUs following this path's recorded sign patterns (same-mask; the docstring
+    of this file says why).  Batch 4, not 2: the ASPP image-pooling BatchNorm normalises over `batch` values per channel
+    and is ill-conditioned at two (test_whole_model).  At this size the production tile planners run (129 x 129, 65 x 65
+    and 33 x 33 maps: > 256 tiles per launch, multi-split weight gradients, parity-ordered strided data gradients)."""
+    from iswm_amd.utils.loss import CrossEntropyLoss
+    from oracle import loss as oloss
+    from oracle.deeplab import OracleDeepLab
+    from oracle.synth import synth_images, synth_labels
+    m, cfg, sd = _build("resnet50", 16)
+    x = synth_images(4, 513, 513, seed=31)
+    lab = synth_labels(4, 513, 513, seed=31, p_fg=0.1, p_ignore=0.02)
+    w = torch.tensor([1.0, 3.0])
+    m.eval()
+    with torch.no_grad():
+        lg_e = m(x[:2].to(dev())).cpu()
+        ref_e = OracleDeepLab(cfg, sd, dropout_p=0.0).eval()(x[:2])
+    assert rel_err(lg_e, ref_e) <= RTOL
+    del lg_e, ref_e
+    m.train()
+    with record_masks(m, "") as rec:
+        lg = m(x.to(dev()))
+    loss = CrossEntropyLoss(weight=w, ignore_index=255)(lg, lab.to(dev()))
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()
+    o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
+    o.relu_masks, o.preact = rec.masks(), {}
+    lgo = o(x)
+    assert rel_err(lg, lgo.detach()) <= RTOL
+    lo = oloss.weighted_ce(lgo, lab, w)
+    assert rel_err(loss, lo.detach()) <= RTOL
+    lo.backward()
+    check_sign_patterns(o, o.relu_masks)
+    params = dict(m.named_parameters())
+    worst = max((rel_err(params[k].grad, v.grad), k) for k, v in o.named_parameters())
+    assert worst[0] <= 3 * RTOL, worst
+    msd = m.state_dict()
+    for k, v in o.state_dict().items():
+        if "running_" in k:
+            assert rel_err(msd[k], v) <= RTOL, k
 
 
 def test_full_size_properties():

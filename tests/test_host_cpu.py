@@ -338,3 +338,40 @@ def test_resume_scoring_of_a_reference_checkpoint():
     assert scalar_score({"Foreground IoU": 0.5, "Foreground F1": 0.7}, 0.63) == 0.63
     assert abs(scalar_score({"Foreground IoU": 0.5, "Foreground F1": 0.7}) - 0.6) < 1e-12
 
+
+def test_planes_predicate_matches_the_kernel_preconditions():
+    """iswm_conv2d_wgrad_planes_ok must say no exactly where iswm_conv2d_wgrad_planes would refuse:
+    sizes beyond the 2^30-element indexing bound and unaligned pitches fall back to the fp32-input weight gradient"""
+    import ctypes
+    from iswm_amd import _lib
+    from iswm_amd._lib import ConvDesc
+    lib = _lib.load()
+    ok = lambda *a: lib.iswm_conv2d_wgrad_planes_ok(ctypes.byref(ConvDesc(*a)))
+    assert ok(16, 33, 33, 256, 33, 33, 256, 3, 3, 1, 1, 1, 256, 256) == 1
+    assert ok(16, 33, 33, 256, 33, 33, 256, 3, 3, 1, 1, 1, 260, 256) == 0        # pitch not a multiple of 8
+    assert ok(16, 33, 33, 252, 33, 33, 256, 3, 3, 1, 1, 1, 256, 256) == 0        # channels not a multiple of 8
+    assert ok(64, 513, 513, 64, 513, 513, 64, 3, 3, 1, 1, 1, 64, 64) == 0        # 2^30 elements and beyond
+    assert ok(16, 33, 33, 256, 32, 33, 256, 3, 3, 1, 1, 1, 256, 256) == 0        # output size does not match geometry
+
+
+def test_fused_adam_loads_a_stock_checkpoint_with_stateless_parameters():
+    """a torch.optim.AdamW state_dict has no entry for a parameter that never received a gradient (a frozen layer of the
+    reference's run): loading it must not raise, the frozen parameter keeps zero moments, the others land in the arena"""
+    from iswm_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    a, b, c = (torch.nn.Parameter(torch.randn(4, 3)) for _ in range(3))
+    ref = torch.optim.AdamW([a, b, c], lr=1e-3, weight_decay=1e-2)
+    a.grad, c.grad = torch.randn(4, 3), torch.randn(4, 3)           # b stays without a gradient -> no state entry
+    ref.step()
+    ref.step()
+    sd = ref.state_dict()
+    assert 1 not in sd["state"]
+    p = [torch.nn.Parameter(t.detach().clone()) for t in (a, b, c)]
+    opt = FusedAdamW(p, lr=1e-3, weight_decay=1e-2)
+    opt.load_state_dict(sd)
+    assert opt._t == 2
+    assert torch.equal(opt.state[p[0]]["exp_avg"], ref.state[a]["exp_avg"])
+    assert torch.equal(opt.state[p[2]]["exp_avg_sq"], ref.state[c]["exp_avg_sq"])
+    assert float(opt.state[p[1]]["exp_avg"].abs().max()) == 0.0 and int(opt.state[p[1]]["step"]) == 0
+    for i, q in enumerate(p):                                        # the state tensors ARE the arena views
+        assert opt.state[q]["exp_avg"].data_ptr() == opt.arena.view_of(opt._m, i).data_ptr()

@@ -133,9 +133,11 @@ def test_class_weights():
 def test_whole_model(tag, backbone, os_):
     fx = load("model_%s.npz" % tag)
     cfg = ArchCfg("deeplabv3plus", backbone, 2, os_)
-    o = OracleDeepLab(cfg, synth_state_dict(cfg), dropout_p=0.0)
-    x = synth_images(2, 65, 65, seed=71)
+    from oracle.make_golden import model_input, model_state
+    o = OracleDeepLab(cfg, model_state(tag, cfg), dropout_p=0.0)
+    x = model_input(tag)[0]
     labels = torch.from_numpy(fx["labels"].astype(np.int64))
+    assert tuple(labels.shape) == (x.shape[0],) + tuple(x.shape[2:])
     with torch.no_grad():
         lg = o.eval()(x)
     assert rel_err(lg, fx["eval_logits"]) <= 1e-4

@@ -5,6 +5,7 @@ Kernel level vs stock fp32 ATen ops on the CPU (same bounds as tests/test_hip_ke
 format itself promises: split -> join is the identity bit for bit, and a network evaluated with pre-split activations
 matches the same network on fp32 activations to fp32 rounding."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -288,7 +289,12 @@ def test_frozen_parameters_are_not_touched_by_the_fused_optimizers():
 
 def test_baseline_config2_per_gpu_workload():
     """BASELINE.json configs[2] as one GPU sees it: deeplabv3plus_resnet101 os16, 16 x 513 x 513, one training step --
-    finite loss, a bit-identical repeat, and the bf16x6 arithmetic against the exact-fp32 MFMA kernels"""
+    finite loss, a bit-identical repeat, and EVERY parameter gradient of the production kernels (k_conv_pl2, k_wgrad_plw
+    with their tile / split planners at M up to 266 256 rows) against the same step on the exact-fp32 MFMA kernels
+    (k_conv_fwd / k_conv_dgrad / k_conv_wgrad: different kernels, planners and data layout end to end).  Bound: relative
+    L2 per tensor.  Two fp32-grade evaluations of this graph differ by rounding in ~1e-6 of the ReLU signs; at 4.2 M
+    values per BatchNorm channel a flipped sign moves a gradient by O(1e-7), so -- unlike the 65 x 65 golden cases -- the
+    bound can stay tight: a pixel range, tile row or K split dropped by a planner moves the tensor's L2 error to O(1)."""
     from iswm_amd import _lib
     from iswm_amd.network import modeling
     from iswm_amd.utils.loss import CrossEntropyLoss
@@ -308,15 +314,27 @@ def test_baseline_config2_per_gpu_workload():
             p.grad = None
         loss = crit(m(x), lab)
         loss.backward()
-        return loss.detach().clone(), m.backbone.conv1.weight.grad.detach().clone(), m.classifier.classifier[6].weight.grad.detach().clone()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
 
-    l1, g1, h1 = run()
-    l2, g2, h2 = run()
-    assert bool(torch.isfinite(l1)) and torch.equal(l1, l2) and torch.equal(g1, g2) and torch.equal(h1, h2)
+    l1, g1 = run()
+    l2, g2 = run()
+    assert bool(torch.isfinite(l1)) and torch.equal(l1, l2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k                            # no atomics anywhere: bit-identical repeat
+    del g2
     old = lib.iswm_get_conv_math()
     try:
         lib.iswm_set_conv_math(0)
-        l3, _, _ = run()
+        l3, g3 = run()
     finally:
         lib.iswm_set_conv_math(old)
     assert abs(float(l1) - float(l3)) <= 1e-4 * abs(float(l3))
+    worst = (0.0, "")
+    for k in g1:
+        a, b = g1[k].double().flatten(), g3[k].double().flatten()
+        assert bool(torch.isfinite(a).all()), k
+        worst = max(worst, (float((a - b).norm() / (b.norm() + 1e-300)), k))
+    if os.environ.get("ISWM_TEST_REPORT"):
+        with open(os.environ["ISWM_TEST_REPORT"], "a") as f:
+            f.write("config2 bf16x6 vs f32-mfma gradients: worst relative L2 %.3e (%s)\n" % worst)
+    assert worst[0] <= 1e-4, worst

@@ -1,19 +1,19 @@
 """whole-model train-mode logits of this path vs (a) the reference's golden vector (torch CPU fp32) and (b) the oracle
-evaluated in float64 -- separates this path's own rounding error from the reference's (r101 / os8 on 65x65, batch 2: the
-ill-conditioned case of tests/test_hip_modules.py::test_whole_model)."""
+evaluated in float64 -- separates this path's own rounding error from the reference's (inputs: oracle/make_golden.py MODEL_INPUT)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.util import load, rel_err
 from iswm_amd.network import modeling
 from oracle.deeplab import OracleDeepLab
-from oracle.synth import ArchCfg, synth_state_dict, synth_images
+from oracle.make_golden import model_input, model_state
+from oracle.synth import ArchCfg, synth_state_dict
 
 for tag, backbone, os_ in (("r50_os16", "resnet50", 16), ("r101_os8", "resnet101", 8)):
     fx = load("model_%s.npz" % tag)
     cfg = ArchCfg("deeplabv3plus", backbone, 2, os_)
-    sd = synth_state_dict(cfg)
-    x = synth_images(2, 65, 65, seed=71)
+    sd = model_state(tag, cfg)
+    x = model_input(tag)[0]
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     o64 = OracleDeepLab(cfg, sd64, dropout_p=0.0).train()
     with torch.no_grad():
