@@ -82,7 +82,9 @@ def test_production_geometry_vs_float64(case):
     ones, zeros = torch.ones(cout, device=dev()), torch.zeros(cout, device=dev())
     coef = ops.bn_finalize(partials, tiles[0], cnt, tiles[1], ones, zeros, zeros.clone(), ones.clone(), 0.1)
     yc = y_ref.permute(1, 0, 2, 3).reshape(len(co), -1)
-    assert rel_err(coef[2].cpu()[co], yc.mean(1)) <= 2e-5
+    # the batch mean against the spread of the values it averages (a mean of 17 424 ... 266 256 roughly centred values is
+    # itself ~1e-2 of that spread: relative to its own size the fp32 tile sums would be asked for more than fp32 holds)
+    assert float(((coef[2].cpu()[co].double() - yc.mean(1)).abs() / yc.std(1)).max()) <= 2e-6
     assert rel_err(1.0 / coef[3].cpu()[co] ** 2, yc.var(1, unbiased=False) + 1e-5) <= 1e-4
     del yh, y_ref, yc
 
