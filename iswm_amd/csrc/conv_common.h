@@ -140,6 +140,8 @@ __device__ __forceinline__ void pack_weights_pl2_body(const float* __restrict__ 
 // second-generation planes kernel: (16*rbw) x 128 tiles, one workgroup per CU (conv_mfma_pl2.hip)
 int pack_job_blocks_pl2(int Cout, int T, int Cin, bool dgrad);
 int conv_pl2_pick_rbw(int64_t M, int cols);
+void conv_pl2_plan(int64_t M, int cols, int K, bool wide_ok, int* rbw, int* wide);      // tile height and 128- / 256-column form
+bool launch_conv_pl2w(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw);  // conv_mfma_pl2w.hip
 bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw);
 size_t packed_weight_bytes_pl2(int Cout, int T, int Cin, bool dgrad, int planes);
 void launch_pack_weights_pl2(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s);

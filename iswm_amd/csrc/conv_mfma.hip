@@ -831,6 +831,14 @@ static PatchArgs patch_args(const iswm_conv_desc* d, bool dgrad, int PH, int PW)
 
 namespace iswm { int wgrad_pl_is_wide(const iswm_conv_desc* d); }
 
+// may this geometry run the 256-column planes kernel (conv_mfma_pl2w.hip)?  bf16x6 only; strided data gradients keep the
+// parity-ordered rows of k_conv_pl2
+static bool pl2_wide_ok(const iswm_conv_desc* d, bool dgrad) {
+    if (math_planes() != 3 || (dgrad && d->stride != 1)) return false;
+    return !dgrad || d->KH * d->KW * d->Cout >= 512;          // the data gradient needs 8 stages per tile to pay
+}
+static int pl2_K(const iswm_conv_desc* d, bool dgrad) { return d->KH * d->KW * (dgrad ? d->Cout : d->Cin); }
+
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
     ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 7, "kernel_name: bad argument");
     if (kind == 7) {   // iswm_conv2d_wgrad_planes
@@ -840,8 +848,10 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
     if (kind >= 5) {   // 5 / 6: iswm_conv2d_fwd_pl2 / iswm_conv2d_dgrad_pl2
         const bool dg = kind == 6;
         const int cols = dg ? d->Cin : d->Cout;
-        const int rbw = conv_pl2_pick_rbw(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, cols);
-        if (cols <= 64) snprintf(buf, buflen, "k_conv_pl2<%d, 2, %d, %s, false, 0>", rbw / 2, math_planes(), dg ? "true" : "false");
+        int rbw, wide;
+        conv_pl2_plan(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, cols, pl2_K(d, dg), pl2_wide_ok(d, dg), &rbw, &wide);
+        if (wide) snprintf(buf, buflen, "k_conv_pl2w<%d, %d, %s>", rbw, math_planes(), dg ? "true" : "false");
+        else if (cols <= 64) snprintf(buf, buflen, "k_conv_pl2<%d, 2, %d, %s, false, 0>", rbw / 2, math_planes(), dg ? "true" : "false");
         else snprintf(buf, buflen, "k_conv_pl2<%d, 1, %d, %s, false, 0>", rbw, math_planes(), dg ? "true" : "false");
         return 0;
     }
@@ -1176,7 +1186,10 @@ extern "C" int iswm_conv2d_pl2_pack_weights(const iswm_conv_desc* d, int kind, c
 
 extern "C" int iswm_conv2d_pl2_tile_rows(const iswm_conv_desc* d, int kind) {
     if (!d) return 0;
-    return 16 * (kind ? conv_pl2_pick_rbw((int64_t)d->N * d->H * d->W, d->Cin) : conv_pl2_pick_rbw((int64_t)d->N * d->Ho * d->Wo, d->Cout));
+    int rbw, wide;
+    if (kind) conv_pl2_plan((int64_t)d->N * d->H * d->W, d->Cin, pl2_K(d, true), pl2_wide_ok(d, true), &rbw, &wide);
+    else conv_pl2_plan((int64_t)d->N * d->Ho * d->Wo, d->Cout, pl2_K(d, false), pl2_wide_ok(d, false), &rbw, &wide);
+    return 16 * rbw;
 }
 
 extern "C" int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
@@ -1191,7 +1204,11 @@ extern "C" int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int6
     a.xps = plane_stride * 2;
     a.M = d->N * d->Ho * d->Wo;
     a.Ktot = d->KH * d->KW * d->Cin;
-    ISWM_REQUIRE(launch_conv_pl2(a, (hipStream_t)stream, false, math_planes(), conv_pl2_pick_rbw(a.M, d->Cout)), "conv_fwd_pl2: no kernel for this configuration");
+    int rbw, wide;
+    conv_pl2_plan(a.M, d->Cout, pl2_K(d, false), pl2_wide_ok(d, false), &rbw, &wide);
+    ISWM_REQUIRE(wide ? launch_conv_pl2w(a, (hipStream_t)stream, false, math_planes(), rbw)
+                      : launch_conv_pl2(a, (hipStream_t)stream, false, math_planes(), rbw),
+                 "conv_fwd_pl2: no kernel for this configuration");
     return check_launch("conv_fwd_pl2");
 }
 
@@ -1208,7 +1225,11 @@ static int dgrad_pl2_impl(const iswm_conv_desc* d, const void* dyp, int64_t plan
     a.M = d->N * d->H * d->W;
     a.Ktot = d->KH * d->KW * d->Cout;
     if (f) a.bnf = *f;
-    ISWM_REQUIRE(launch_conv_pl2(a, (hipStream_t)stream, true, math_planes(), conv_pl2_pick_rbw(a.M, d->Cin)), "conv_dgrad_pl2: no kernel for this configuration");
+    int rbw, wide;
+    conv_pl2_plan(a.M, d->Cin, pl2_K(d, true), pl2_wide_ok(d, true), &rbw, &wide);
+    ISWM_REQUIRE(wide ? launch_conv_pl2w(a, (hipStream_t)stream, true, math_planes(), rbw)
+                      : launch_conv_pl2(a, (hipStream_t)stream, true, math_planes(), rbw),
+                 "conv_dgrad_pl2: no kernel for this configuration");
     return check_launch("conv_dgrad_pl2");
 }
 
@@ -1221,7 +1242,8 @@ extern "C" int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, i
 extern "C" int iswm_conv2d_dgrad_pl2_stat_tiles(const iswm_conv_desc* d) {
     if (!d || d->Cin <= 0) return 0;
     const int64_t M = (int64_t)d->N * d->H * d->W;
-    const int rbw = conv_pl2_pick_rbw(M, d->Cin);
+    int rbw, wide;
+    conv_pl2_plan(M, d->Cin, pl2_K(d, true), pl2_wide_ok(d, true), &rbw, &wide);
     const int wm = d->Cin <= 64 ? 2 : 1;                 // narrow tiles: (rbw / 2) blocks x 2 wave rows
     const int64_t mt = (M + rbw * 16 - 1) / (rbw * 16);
     return (int)(mt * wm);

@@ -566,6 +566,39 @@ int conv_pl2_pick_rbw(int64_t M, int cols) {
     return best;
 }
 
+// Tile plan: height (rbw 16-row blocks) and width.  256-column tiles (k_conv_pl2w: two column blocks per wave, ~15 % less
+// time per MFMA) are taken where the tile count still covers the chip:  cost = rounds x (rows + fixed) x (2 x 0.85 if wide).
+void conv_pl2_plan(int64_t M, int cols, int K, bool wide_ok, int* rbw_out, int* wide_out) {
+    static int force = -2;
+    static double eff = 0.85;
+    if (force == -2) {
+        force = getenv("ISWM_PL2_WIDE") ? atoi(getenv("ISWM_PL2_WIDE")) : -1;        // 0: never, 1: wherever possible
+        if (const char* e = getenv("ISWM_PL2W_EFF")) eff = atof(e) > 0 ? atof(e) : eff;
+    }
+    *rbw_out = conv_pl2_pick_rbw(M, cols);
+    *wide_out = 0;
+    // short K: a tile is a few stages and then an epilogue of twice the size -- measured slower below 4 stages (forward)
+    // / 8 stages (data gradient, whose accumulating epilogue also reads) [profiles/r03_pl2w_ab.txt]
+    if (!wide_ok || cols < 256 || force == 0 || (force != 1 && K < 256)) return;
+    const int64_t NT = (cols + 127) / 128, NTW = (cols + 255) / 256;
+    double best = 1e300;
+    {
+        const int rbw = *rbw_out;
+        const int64_t MT = (M + rbw * 16 - 1) / (rbw * 16);
+        best = (double)((MT * NT + 255) / 256) * (rbw * 16 + 24.0);
+        if (force == 1) best = 1e300;
+    }
+    for (int rbw = 8; rbw <= PL2_RBWMAX; ++rbw) {
+        const int64_t MT = (M + rbw * 16 - 1) / (rbw * 16);
+        const double c = (double)((MT * NTW + 255) / 256) * (rbw * 16 + 24.0) * 2.0 * eff;
+        if (c < best - 1e-9) {
+            best = c;
+            *rbw_out = rbw;
+            *wide_out = 1;
+        }
+    }
+}
+
 // rbw = 16-row blocks per tile (8..10 instantiated for 128-column tiles; 2 x 4/5 for 64-column tiles)
 bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw) {
     static int parity = -1, ncu = 0;
