@@ -13,6 +13,8 @@
 // (slabs summed in a fixed order by k_reduce_slabs: bit-reproducible).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace iswm {
@@ -521,6 +523,242 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
     }
 }
 
+// ---- 128 x 256 tile, LOADER and MULTIPLIER waves ("specialised").
+// In k_wgrad_plw all eight waves do everything in lockstep: after the step's barrier each of them advances its pixel, builds
+// three source addresses, issues 9 DMA instructions, reads its first fragments -- and only then starts its 48 MFMAs; the two
+// waves of a SIMD cannot cover each other because the barrier keeps them in phase, so every one of those sections lengthens
+// the step (profiles/r02_wgrad_model.txt: 3 086 cycles of matrix work per step, ~6 100 measured).  A deeper DMA ring by
+// itself does not help (tried: 16-pixel steps through four buffers, all waves still doing everything: 11-13 % SLOWER, isolated
+// and in the network -- the step is not waiting for memory, profiles/r03_wgrad_ring.txt).
+// Here the roles are split.  Waves 4-7 are LOADERS: each stands on 4 of a stage's 16 pixel rows, does the pixel bookkeeping
+// and issues the stage's 36 DMA pieces (9 per loader), three stages ahead through a ring of four 36-KB buffers, and waits
+// for a stage to land before it joins that stage's barrier.  Waves 0-3 are MULTIPLIERS, one per SIMD: a 64 x 128 block of the
+// tile each (128 accumulator registers), 48 MFMAs of 32x32x16 per 16-pixel stage with the transposing fragment reads in
+// the gaps; between two barriers a multiplier executes nothing but reads and MFMAs.
+// Stages whose gathered pixels are all padding are not skipped (no workgroup-wide vote: it would put the multipliers back
+// in the loaders' lockstep) -- the deep-padding ASPP shapes stay on k_wgrad_plw.
+template <int NP, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
+    constexpr int KS = 16;                     // pixels per stage
+    constexpr int PLANE = KS * 256;            // bytes of one plane of one 128-channel image of one stage
+    constexpr int IMG = NP * PLANE;
+    constexpr int STAGE = 3 * IMG;             // A image, then the two B images
+    constexpr int NST = 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_vptr3)smem;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tiles = a.MT * a.NT;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = L / tiles, tile = L - split * tiles;
+    const int mt = tile / a.NT, nt = tile - mt * a.NT;
+    const int m0 = mt * 128, n0 = nt * 256;
+    const int p_begin = split * a.psplit;
+    const int p_end = min(a.P, p_begin + a.psplit);
+    const int nK = (p_end - p_begin + KS - 1) / KS;
+
+    if (wave >= 4) {
+        // ================= loader =================
+        const int rg = wave - 4;                               // 4-row group of the stage
+        const int kr = 4 * rg + (lane >> 4);
+        const int gsrc = (lane & 15) ^ (4 * ((lane >> 4) & 3));
+        const unsigned char* zrow = reinterpret_cast<const unsigned char*>(g_zero_row_wg) + (lane & 15) * 16;
+        const int ach = m0 + 8 * gsrc;
+        const bool aok = ach < a.Cout;
+        const unsigned char* abase = reinterpret_cast<const unsigned char*>(a.dy) + (size_t)ach * 2;
+        bool bok[2];
+        int dh[2], dw[2];
+        const unsigned char* bbase[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int bcol = n0 + 128 * i + 8 * gsrc;
+            bok[i] = bcol < a.Ktot;
+            const int tap = bok[i] ? bcol / a.Cin : 0, bch = bok[i] ? bcol - tap * a.Cin : 0;
+            const int tkh = tap / a.KW, tkw = tap - tkh * a.KW;
+            dh[i] = tkh * a.dil - a.pad;
+            dw[i] = tkw * a.dil - a.pad;
+            bbase[i] = reinterpret_cast<const unsigned char*>(a.x) + (size_t)bch * 2;
+        }
+        const int HoWo = a.Ho * a.Wo;
+        int pn, poh, pow_;
+        {
+            const int p = p_begin + kr;
+            pn = p / HoWo;
+            const int rem = p - pn * HoWo;
+            poh = rem / a.Wo;
+            pow_ = rem - poh * a.Wo;
+        }
+        const int d_oh = KS / a.Wo, d_ow = KS - d_oh * a.Wo;
+        const bool fast_adv = d_oh + 1 <= a.Ho;
+        // DMA of stage kc into its ring slot
+        auto issue = [&](int kc) __attribute__((always_inline)) {
+            const int p = p_begin + kc * KS + kr;
+            const bool pin = p < p_end;
+            const unsigned char* asrc = (pin && aok) ? abase + (size_t)p * a.ldy * 2 : zrow;
+            const long long apst = (pin && aok) ? a.dyps : 0;
+            const unsigned char* bsrc[2];
+            long long bpst[2];
+            if (a.always) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool v = pin && bok[i];
+                    bsrc[i] = v ? bbase[i] + (size_t)p * a.ldx * 2 : zrow;
+                    bpst[i] = v ? a.xps : 0;
+                }
+            } else {
+                if (kc > 0) {
+                    if (fast_adv) {
+                        int ow = pow_ + d_ow;
+                        const int c1 = ow >= a.Wo ? 1 : 0;
+                        pow_ = ow - (c1 ? a.Wo : 0);
+                        int oh = poh + d_oh + c1;
+                        const int c2 = oh >= a.Ho ? 1 : 0;
+                        poh = oh - (c2 ? a.Ho : 0);
+                        pn += c2;
+                    } else {
+                        pn = p / HoWo;
+                        const int rem = p - pn * HoWo;
+                        poh = rem / a.Wo;
+                        pow_ = rem - poh * a.Wo;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ih = poh * a.stride + dh[i], iw = pow_ * a.stride + dw[i];
+                    const bool v = pin && bok[i] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                    bsrc[i] = v ? bbase[i] + (size_t)((pn * a.H + ih) * a.W + iw) * a.ldx * 2 : zrow;
+                    bpst[i] = v ? a.xps : 0;
+                }
+            }
+            const unsigned dst = lds_base + (kc & 3) * STAGE + rg * 1024;
+            if constexpr (ABL & 1) return;              // timing ablation: no DMA
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) glds16w(asrc + pl * apst, dst + pl * PLANE);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) glds16w(bsrc[i] + pl * bpst[i], dst + (1 + i) * IMG + pl * PLANE);
+        };
+        const int pre = nK < 3 ? nK : 3;
+        for (int kc = 0; kc < pre; ++kc) issue(kc);
+        for (int s2 = 0; s2 < nK; ++s2) {
+            // stage s2 must have landed; stages issued beyond it (<= 2) may stay in flight: 3 NP pieces each
+            const int beyond = min(nK - 1, s2 + 2) - s2;
+            if constexpr (NP == 3) {
+                if (beyond >= 2) __builtin_amdgcn_s_waitcnt(0x4F72);        // vmcnt(18)
+                else if (beyond == 1) __builtin_amdgcn_s_waitcnt(0x0F79);   // vmcnt(9)
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            } else {
+                if (beyond >= 2) __builtin_amdgcn_s_waitcnt(0x0F76);        // vmcnt(6)
+                else if (beyond == 1) __builtin_amdgcn_s_waitcnt(0x0F73);   // vmcnt(3)
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            __builtin_amdgcn_s_barrier();          // B(s2): the multipliers are done with stage s2 - 1, its buffer is free
+            asm volatile("" ::: "memory");
+            if (s2 + 3 < nK) issue(s2 + 3);
+        }
+        return;
+    }
+
+    // ================= multiplier =================
+    const int wm = wave >> 1, wn = wave & 1;           // rows 64 wm .., the B image 1 + wn (128 columns)
+    const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+    const int th = tg >> 1, tc = (tg & 1) * 16 + tp * 4;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    auto tr_frag = [&](const unsigned char* plane, int col0) __attribute__((always_inline)) -> uint4 {
+        const unsigned char* p = plane + (th * 8 + tq) * 256 + (((col0 + tc) * 2) ^ (tq * 64));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 256));
+        uint2 a2 = __builtin_bit_cast(uint2, lo), b2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(a2.x, a2.y, b2.x, b2.y);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    uint4 FA[2][NP], FB[4][NP];
+    auto ldA = [&](int slot, int mb) __attribute__((always_inline)) {
+        const unsigned char* Ax = smem + slot * STAGE;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) FA[mb][pl] = tr_frag(Ax + pl * PLANE, wm * 64 + mb * 32);
+    };
+    auto ldB = [&](int slot, int nb) __attribute__((always_inline)) {
+        const unsigned char* Bx = smem + slot * STAGE + (1 + wn) * IMG;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) FB[nb][pl] = tr_frag(Bx + pl * PLANE, nb * 32);
+    };
+    auto mm = [&](int mb, int nb) __attribute__((always_inline)) {
+        f32x16 c = acc[mb][nb];
+        if constexpr (ABL & 2) {                        // timing ablation: one MFMA per block instead of six
+            c = mfma_bf16(FA[mb][0] ^ FA[mb][1] ^ FA[mb][2], FB[nb][0] ^ FB[nb][1] ^ FB[nb][2], c);
+            acc[mb][nb] = c;
+            return;
+        }
+        if constexpr (NP == 3) {
+            c = mfma_bf16(FA[mb][2], FB[nb][0], c);     // smallest terms first
+            c = mfma_bf16(FA[mb][0], FB[nb][2], c);
+            c = mfma_bf16(FA[mb][1], FB[nb][1], c);
+            c = mfma_bf16(FA[mb][1], FB[nb][0], c);
+            c = mfma_bf16(FA[mb][0], FB[nb][1], c);
+        }
+        c = mfma_bf16(FA[mb][0], FB[nb][0], c);
+        acc[mb][nb] = c;
+    };
+#define ISWM_SB() __builtin_amdgcn_sched_barrier(0)
+    for (int s2 = 0; s2 < nK; ++s2) {
+        __builtin_amdgcn_s_barrier();              // B(s2): stage s2 has landed
+        asm volatile("" ::: "memory");
+        const int slot = s2 & 3;
+        // 8 blocks of 6 MFMAs; every fragment group is read one block before the block that needs it
+        ldA(slot, 0); ldB(slot, 0);
+        ISWM_SB(); ldB(slot, 1); ISWM_SB(); mm(0, 0); ISWM_SB();
+        ISWM_SB(); ldB(slot, 2); ISWM_SB(); mm(0, 1); ISWM_SB();
+        ISWM_SB(); ldB(slot, 3); ISWM_SB(); mm(0, 2); ISWM_SB();
+        ISWM_SB(); ldA(slot, 1); ISWM_SB(); mm(0, 3); ISWM_SB();
+        ISWM_SB(); mm(1, 3); ISWM_SB();
+        ISWM_SB(); mm(1, 2); ISWM_SB();
+        ISWM_SB(); mm(1, 1); ISWM_SB();
+        ISWM_SB(); mm(1, 0); ISWM_SB();
+        // all reads of the stage were waited for by the MFMAs that consumed them: the next barrier may free its buffer
+    }
+#undef ISWM_SB
+
+    // slab / result layout of k_wgrad_plw (k_reduce_slabs_frag): its "wave" w8 = 4 wm + (64-column group), block (mb, nb & 1)
+    if (a.nsplit > 1) {
+        float4* slab = reinterpret_cast<float4*>(a.out) + ((size_t)split * tiles + tile) * 8192 + lane;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int w8 = wm * 4 + wn * 2 + (nb >> 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    slab[(size_t)w8 * 1024 + ((mb * 2 + (nb & 1)) * 4 + q) * 64] =
+                        make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
+            }
+        return;
+    }
+    float* out = a.out;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int col = n0 + wn * 128 + nb * 32 + li;
+        const bool cok = col < a.Ktot;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < a.Cout) out[(size_t)row * a.Ktot + col] = acc[mb][nb][r];
+            }
+    }
+}
+
 // sum of the accumulator-order slabs of k_wgrad_plw over the splits (fixed order: bit-reproducible), scattered into dw:
 // float4 f of tile t holds rows m0 + 64 wm + 32 mb + 8 q + 4 (lane >> 5) + 0..3 of column n0 + 64 wn + 32 nb + (lane & 31)
 __global__ __launch_bounds__(256) void k_reduce_slabs_frag(const float4* __restrict__ slabs, float* __restrict__ dw, int tiles,
@@ -611,6 +849,18 @@ void plan_wgrad_pl(int Cout, int Ktot, int taps, int64_t P, int* nsplit, int* ps
 
 void launch_wgrad_pl(const WgArgs& a, int planes, int wide, hipStream_t s) {
     dim3 grid(a.MT * a.NT * a.nsplit), blk(512);
+    static int spec = -1;
+    if (spec < 0) spec = getenv("ISWM_WG_SPEC") ? atoi(getenv("ISWM_WG_SPEC")) : 1;
+    if (wide && spec && !a.vote && a.abl == 0 && a.dbg == nullptr) {
+        static int sabl = -1;
+        if (sabl < 0) sabl = getenv("ISWM_WGS_ABL") ? atoi(getenv("ISWM_WGS_ABL")) : 0;
+        if (planes == 1) hipLaunchKernelGGL(k_wgrad_pls<1>, grid, blk, 0, s, a);
+        else if (sabl == 1) hipLaunchKernelGGL((k_wgrad_pls<3, 1>), grid, blk, 0, s, a);
+        else if (sabl == 2) hipLaunchKernelGGL((k_wgrad_pls<3, 2>), grid, blk, 0, s, a);
+        else if (sabl == 3) hipLaunchKernelGGL((k_wgrad_pls<3, 3>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL(k_wgrad_pls<3>, grid, blk, 0, s, a);
+        return;
+    }
     if (wide) {
         if (planes == 1) hipLaunchKernelGGL(k_wgrad_plw<1>, grid, blk, 0, s, a);
         else if (a.abl == 1) hipLaunchKernelGGL((k_wgrad_plw<3, false, 1>), grid, blk, 0, s, a);

@@ -36,7 +36,7 @@ def med(fn):
 
 
 print("env:", {k: v for k, v in os.environ.items() if k.startswith("ISWM_")})
-tot = 0.0
+tot = totw = 0.0
 for c in CASES:
     n, h, w, cin, cout, k, s, p, d = c
     tag = "n%d %dx%d c%d->%d k%d s%d d%d" % (n, h, w, cin, cout, k, s, d)
@@ -69,7 +69,14 @@ for c in CASES:
         td = med(lambda: ops.conv2d_dgrad(dy, wt, g, (n, h, w, cin), dx=dx, wpk2=wpk1))
         ta = med(lambda: ops.conv2d_dgrad(dy, wt, g, (n, h, w, cin), dx=dx, accumulate=True, wpk2=wpk1))
     fl = g.flops()
-    print("%-34s fwd %7.1f us %6.1f TF %-28s| dgrad %7.1f us %6.1f TF  acc %7.1f us  %s" %
-          (tag, tf, fl / tf / 1e6, _kernel_name(d0, 5), td, fl / td / 1e6, ta, _kernel_name(d1, 6) if nb else "-"))
+    dw = torch.empty(cout, k, k, cin, device=dev)
+    for _ in range(2):
+        ops.conv2d_wgrad(x, dy, g, dw)
+    tw = med(lambda: ops.conv2d_wgrad(x, dy, g, dw))
+    d7 = ops.ConvDesc(n, h, w, cin, g.ho, g.wo, cout, k, k, s, p, d, pgeom(x)[4], pgeom(dy)[4])
+    print("%-34s fwd %7.1f us %6.1f TF %-28s| dgrad %7.1f us %6.1f TF  acc %7.1f us  %s | wgrad %7.1f us %6.1f TF %s" %
+          (tag, tf, fl / tf / 1e6, _kernel_name(d0, 5), td, fl / td / 1e6, ta, _kernel_name(d1, 6) if nb else "-",
+           tw, fl / tw / 1e6, _kernel_name(d7, 7)))
     tot += tf + (td if nb else 0)
-print("sum fwd + dgrad: %.1f us" % tot)
+    totw += tw
+print("sum fwd + dgrad: %.1f us   sum wgrad: %.1f us" % (tot, totw))
