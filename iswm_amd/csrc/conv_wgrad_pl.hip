@@ -537,8 +537,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_plw(const WgArgs a) {
 // the gaps; between two barriers a multiplier executes nothing but reads and MFMAs.
 // Stages whose gathered pixels are all padding are not skipped (no workgroup-wide vote: it would put the multipliers back
 // in the loaders' lockstep) -- the deep-padding ASPP shapes stay on k_wgrad_plw.
-template <int NP, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
+// MW: multiplier waves -- 4 (one per SIMD, 64 x 128 each) or 8 (two per SIMD, 64 x 64 each; 12 waves per workgroup)
+template <int NP, int ABL = 0, int MW = 4>
+__global__ __launch_bounds__(64 * (MW + 4), (MW + 4) / 4) void k_wgrad_pls(const WgArgs a) {
     constexpr int KS = 16;                     // pixels per stage
     constexpr int PLANE = KS * 256;            // bytes of one plane of one 128-channel image of one stage
     constexpr int IMG = NP * PLANE;
@@ -558,9 +559,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
     const int p_end = min(a.P, p_begin + a.psplit);
     const int nK = (p_end - p_begin + KS - 1) / KS;
 
-    if (wave >= 4) {
+    if (wave >= MW) {
         // ================= loader =================
-        const int rg = wave - 4;                               // 4-row group of the stage
+        const int rg = wave - MW;                              // 4-row group of the stage
         const int kr = 4 * rg + (lane >> 4);
         const int gsrc = (lane & 15) ^ (4 * ((lane >> 4) & 3));
         const unsigned char* zrow = reinterpret_cast<const unsigned char*>(g_zero_row_wg) + (lane & 15) * 16;
@@ -662,7 +663,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
     }
 
     // ================= multiplier =================
-    const int wm = wave >> 1, wn = wave & 1;           // rows 64 wm .., the B image 1 + wn (128 columns)
+    constexpr int NBW = MW == 4 ? 4 : 2;               // 32-column blocks per multiplier
+    const int wm = MW == 4 ? wave >> 1 : wave >> 2;    // rows 64 wm ..
+    const int wn4 = MW == 4 ? 2 * (wave & 1) : (wave & 3);        // first 64-column group of this wave (of 4)
     const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
     const int th = tg >> 1, tc = (tg & 1) * 16 + tp * 4;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -674,23 +677,23 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
         uint2 a2 = __builtin_bit_cast(uint2, lo), b2 = __builtin_bit_cast(uint2, hi);
         return make_uint4(a2.x, a2.y, b2.x, b2.y);
     };
-    f32x16 acc[2][4];
+    f32x16 acc[2][NBW];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NBW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    uint4 FA[2][NP], FB[4][NP];
+    uint4 FA[2][NP], FB[NBW][NP];
     auto ldA = [&](int slot, int mb) __attribute__((always_inline)) {
         const unsigned char* Ax = smem + slot * STAGE;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) FA[mb][pl] = tr_frag(Ax + pl * PLANE, wm * 64 + mb * 32);
     };
     auto ldB = [&](int slot, int nb) __attribute__((always_inline)) {
-        const unsigned char* Bx = smem + slot * STAGE + (1 + wn) * IMG;
+        const unsigned char* Bx = smem + slot * STAGE + (1 + (wn4 >> 1)) * IMG;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) FB[nb][pl] = tr_frag(Bx + pl * PLANE, nb * 32);
+        for (int pl = 0; pl < NP; ++pl) FB[nb][pl] = tr_frag(Bx + pl * PLANE, (wn4 & 1) * 64 + nb * 32);
     };
     auto mm = [&](int mb, int nb) __attribute__((always_inline)) {
         f32x16 c = acc[mb][nb];
@@ -714,16 +717,23 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
         __builtin_amdgcn_s_barrier();              // B(s2): stage s2 has landed
         asm volatile("" ::: "memory");
         const int slot = s2 & 3;
-        // 8 blocks of 6 MFMAs; every fragment group is read one block before the block that needs it
+        // blocks of 6 MFMAs; every fragment group is read one block before the block that needs it
         ldA(slot, 0); ldB(slot, 0);
-        ISWM_SB(); ldB(slot, 1); ISWM_SB(); mm(0, 0); ISWM_SB();
-        ISWM_SB(); ldB(slot, 2); ISWM_SB(); mm(0, 1); ISWM_SB();
-        ISWM_SB(); ldB(slot, 3); ISWM_SB(); mm(0, 2); ISWM_SB();
-        ISWM_SB(); ldA(slot, 1); ISWM_SB(); mm(0, 3); ISWM_SB();
-        ISWM_SB(); mm(1, 3); ISWM_SB();
-        ISWM_SB(); mm(1, 2); ISWM_SB();
-        ISWM_SB(); mm(1, 1); ISWM_SB();
-        ISWM_SB(); mm(1, 0); ISWM_SB();
+        if constexpr (NBW == 4) {
+            ISWM_SB(); ldB(slot, 1); ISWM_SB(); mm(0, 0); ISWM_SB();
+            ISWM_SB(); ldB(slot, 2); ISWM_SB(); mm(0, 1); ISWM_SB();
+            ISWM_SB(); ldB(slot, 3); ISWM_SB(); mm(0, 2); ISWM_SB();
+            ISWM_SB(); ldA(slot, 1); ISWM_SB(); mm(0, 3); ISWM_SB();
+            ISWM_SB(); mm(1, 3); ISWM_SB();
+            ISWM_SB(); mm(1, 2); ISWM_SB();
+            ISWM_SB(); mm(1, 1); ISWM_SB();
+            ISWM_SB(); mm(1, 0); ISWM_SB();
+        } else {
+            ISWM_SB(); ldB(slot, 1); ISWM_SB(); mm(0, 0); ISWM_SB();
+            ISWM_SB(); ldA(slot, 1); ISWM_SB(); mm(0, 1); ISWM_SB();
+            ISWM_SB(); mm(1, 1); ISWM_SB();
+            ISWM_SB(); mm(1, 0); ISWM_SB();
+        }
         // all reads of the stage were waited for by the MFMAs that consumed them: the next barrier may free its buffer
     }
 #undef ISWM_SB
@@ -734,8 +744,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int w8 = wm * 4 + wn * 2 + (nb >> 1);
+            for (int nb = 0; nb < NBW; ++nb) {
+                const int w8 = wm * 4 + wn4 + (nb >> 1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     slab[(size_t)w8 * 1024 + ((mb * 2 + (nb & 1)) * 4 + q) * 64] =
@@ -746,8 +756,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pls(const WgArgs a) {
     float* out = a.out;
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int col = n0 + wn * 128 + nb * 32 + li;
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int col = n0 + wn4 * 64 + nb * 32 + li;
         const bool cok = col < a.Ktot;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -858,6 +868,8 @@ void launch_wgrad_pl(const WgArgs& a, int planes, int wide, hipStream_t s) {
         else if (sabl == 1) hipLaunchKernelGGL((k_wgrad_pls<3, 1>), grid, blk, 0, s, a);
         else if (sabl == 2) hipLaunchKernelGGL((k_wgrad_pls<3, 2>), grid, blk, 0, s, a);
         else if (sabl == 3) hipLaunchKernelGGL((k_wgrad_pls<3, 3>), grid, blk, 0, s, a);
+        else if (sabl == 8) hipLaunchKernelGGL((k_wgrad_pls<3, 0, 8>), grid, dim3(768), 0, s, a);
+        else if (sabl == 9) hipLaunchKernelGGL((k_wgrad_pls<3, 1, 8>), grid, dim3(768), 0, s, a);
         else hipLaunchKernelGGL(k_wgrad_pls<3>, grid, blk, 0, s, a);
         return;
     }
