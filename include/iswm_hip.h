@@ -162,14 +162,17 @@ int iswm_conv2d_dgrad_pl2(const iswm_conv_desc* d, const void* dyp, int64_t plan
  * whose activation the conv read -- reference resnet.py:103-118: bn1 / bn2 of a Bottleneck): per tile row t and input channel c
  *   partials[0][t][c] = sum dz,  partials[1][t][c] = sum dz * xhat,   dz = dx * [ReLU pattern],  xhat = (y - mean) * invstd
  * over the finished dx (after accumulation).  y: that stage's raw conv output [N*H*W][ldy]; relu 0 = no activation, 2 = pattern
- * recomputed as (y - mean) * mask_scale + mask_shift > 0, exactly as iswm_bn_backward does.  partials: 2 * tiles * Cin doubles,
+ * recomputed as (y - mean) * mask_scale + mask_shift > 0, exactly as iswm_bn_backward does; 3 = the producer is a RESIDUAL
+ * stage (bn3 of a Bottleneck, resnet.py:110-118): pattern = hi plane of its saved output planes (mask_hi, pitch ld_mask bf16
+ * elements) > 0, and dx is stored MASKED -- the one tensor is then both dout of that stage's BatchNorm backward (call it with
+ * relu = 0) and the gradient of its identity branch: no reduction pass, no separate dres.  partials: 2 * tiles * Cin doubles,
  * tiles = iswm_conv2d_dgrad_pl2_stat_tiles(d).  iswm_bn_backward_stats_pl then runs only the finalize and apply passes
  * (8 bytes per element of HBM traffic less than iswm_bn_backward_pl). */
 int iswm_conv2d_dgrad_pl2_stat_tiles(const iswm_conv_desc* d);
 int iswm_conv2d_dgrad_pl2_bn(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk, float* dx,
                              int accumulate, const float* y, int ldy, const float* mean, const float* invstd,
-                             const float* mask_scale, const float* mask_shift, int relu, double* partials, int tiles,
-                             iswm_stream_t stream);
+                             const float* mask_scale, const float* mask_shift, int relu, const void* mask_hi,
+                             int ld_mask, double* partials, int tiles, iswm_stream_t stream);
 int iswm_bn_backward_stats_pl(const float* dout, int ldd, const void* out, int ldo, int64_t out_ps, const float* y, int ldy,
                               int64_t M, int C, const float* mean, const float* invstd, const float* gamma,
                               const float* mask_scale, const float* mask_shift, int relu, int training, float* dgamma,

@@ -59,7 +59,8 @@ _SIGS = {
     "iswm_conv2d_fwd_pl2": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, P, P, P]),
     "iswm_conv2d_dgrad_pl2": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P]),
     "iswm_conv2d_dgrad_pl2_stat_tiles": (c_int, [POINTER(ConvDesc)]),
-    "iswm_conv2d_dgrad_pl2_bn": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P, c_int, P, P, P, P, c_int, P, c_int, P]),
+    "iswm_conv2d_dgrad_pl2_bn": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P, c_int, P, P, P, P, c_int, P, c_int, P,
+                                         c_int, P]),
     "iswm_bn_backward_stats_pl": (c_int, [P, c_int, P, c_int, c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, c_int, c_int, P, P,
                                           P, c_int, c_int64, P, c_int, P, c_int, P, c_size_t, P]),
     "iswm_conv2d_wgrad_planes_ok": (c_int, [POINTER(ConvDesc)]),

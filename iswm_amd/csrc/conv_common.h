@@ -19,6 +19,11 @@ struct BnFuse {
     const float* mshift;
     double* part;              // [2][tiles][C]; nullptr = off
     int ldy, relu;
+    // relu == 3: the producer stage is a RESIDUAL stage (out = relu(bn(y) + identity)): its ReLU pattern is read from the hi
+    // plane of its saved output (`mask`, pitch ldm bf16 elements) and the epilogue stores the MASKED gradient dz = dx * [out > 0]
+    // -- that tensor is at once the input of the producer's BatchNorm backward and the gradient of its identity branch
+    const unsigned short* mask;
+    int ldm;
 };
 
 struct ConvArgs {

@@ -1252,15 +1252,21 @@ extern "C" int iswm_conv2d_dgrad_pl2_stat_tiles(const iswm_conv_desc* d) {
 /* iswm_conv2d_dgrad_pl2 that also emits, per tile row and input channel, the two sums the BatchNorm backward of the stage
  * that PRODUCED the conv's input needs over the finished dx (after accumulation):  partials[0][t][c] = sum dz,
  * partials[1][t][c] = sum dz * xhat,  dz = dx * [ReLU pattern], xhat = (y - mean) * invstd.  relu: 0 none, 2 pattern
- * recomputed as (y - mean) * mask_scale + mask_shift > 0 (as iswm_bn_backward does).  y: the producer's raw conv output
+ * recomputed as (y - mean) * mask_scale + mask_shift > 0 (as iswm_bn_backward does), 3 the producer is a RESIDUAL stage:
+ * pattern = (hi plane of its saved output, mask_hi, pitch ld_mask bf16 elements) > 0, and dx is STORED MASKED (dz): that
+ * tensor is both the dout of the producer's BatchNorm backward (call it with relu = 0) and the gradient of its identity
+ * branch, so neither the reduction pass nor a separate `dres` tensor exists for that stage.  y: the producer's raw conv output
  * [N*H*W][ldy], Cin channels.  partials: 2 * tiles * Cin doubles, tiles = iswm_conv2d_dgrad_pl2_stat_tiles(d).  Feed them to
  * iswm_bn_backward_pl with partial_tiles = tiles: it then skips its own reduction pass over dout and y. */
 extern "C" int iswm_conv2d_dgrad_pl2_bn(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
                                         float* dx, int accumulate, const float* y, int ldy, const float* mean,
                                         const float* invstd, const float* mask_scale, const float* mask_shift, int relu,
-                                        double* partials, int tiles, iswm_stream_t stream) {
+                                        const void* mask_hi, int ld_mask, double* partials, int tiles,
+                                        iswm_stream_t stream) {
     ISWM_REQUIRE(d && y && mean && invstd && partials, "conv_dgrad_pl2_bn: null pointer");
-    ISWM_REQUIRE(relu == 0 || (relu == 2 && mask_scale && mask_shift), "conv_dgrad_pl2_bn: relu must be 0 or 2 (with mask_scale / mask_shift)");
+    ISWM_REQUIRE(relu == 0 || (relu == 2 && mask_scale && mask_shift) ||
+                     (relu == 3 && mask_hi && ld_mask % 4 == 0 && ld_mask >= d->Cin && (((uintptr_t)mask_hi) & 7) == 0),
+                 "conv_dgrad_pl2_bn: relu must be 0, 2 (with mask_scale / mask_shift) or 3 (with the producer's saved output planes)");
     ISWM_REQUIRE(d->Cin % 4 == 0 && ldy % 4 == 0 && ldy >= d->Cin && aligned16(y) && aligned16(mean) && aligned16(invstd),
                  "conv_dgrad_pl2_bn: Cin %% 4, ldy %% 4, 16-byte aligned pointers");
     ISWM_REQUIRE(tiles == iswm_conv2d_dgrad_pl2_stat_tiles(d), "conv_dgrad_pl2_bn: tiles %d != %d", tiles,
@@ -1268,6 +1274,7 @@ extern "C" int iswm_conv2d_dgrad_pl2_bn(const iswm_conv_desc* d, const void* dyp
     BnFuse f{};
     f.y = y; f.ldy = ldy; f.mean = mean; f.invstd = invstd; f.mscale = mask_scale; f.mshift = mask_shift; f.relu = relu;
     f.part = partials;
+    f.mask = reinterpret_cast<const unsigned short*>(mask_hi); f.ldm = ld_mask;
     return dgrad_pl2_impl(d, dyp, plane_stride, wpk, dx, accumulate, &f, stream);
 }
 

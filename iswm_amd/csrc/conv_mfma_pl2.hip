@@ -292,6 +292,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         const int col = n0 + 16 * wn + 4 * lq;
         const bool cok = col < NC;
         const bool bnf = DGRAD && a.bnf.part != nullptr;
+        const bool mk = bnf && a.bnf.relu == 3;
         if (DGRAD && a.accumulate && zero && !bnf) return;           // ... adds nothing
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!DGRAD && a.bias != nullptr && cok) bv = *reinterpret_cast<const float4*>(a.bias + col);
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
 #pragma unroll
         for (int h0 = 0; h0 < RBW; h0 += EH) {
             float4 oldv[EH], yvv[EH];
+            uint2 mkv[EH];
             if constexpr (DGRAD) {
 #pragma unroll
                 for (int j = 0; j < EH; ++j) {
@@ -331,10 +333,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
                     const int row = m0 + lrw;
                     oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     yvv[j] = oldv[j];
+                    mkv[j] = make_uint2(0u, 0u);
                     if (rb < RBW && cok && row < a.M) {
                         const int pix = par ? rowpix[lrw] : row;
                         if (a.accumulate) oldv[j] = *reinterpret_cast<const float4*>(&a.y[(size_t)pix * a.ldy + col]);
                         if (bnf) yvv[j] = *reinterpret_cast<const float4*>(a.bnf.y + (size_t)pix * a.bnf.ldy + col);
+                        if (mk) mkv[j] = *reinterpret_cast<const uint2*>(a.bnf.mask + (size_t)pix * a.bnf.ldm + col);
                     }
                 }
             }
@@ -354,7 +358,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
                     } else {
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     }
-                    if (!(DGRAD && a.accumulate && zero)) *o = v;
+                    if (mk) {
+                        // residual producer: the pattern comes from the hi plane of its saved output (as k_bn_bwd_reduce<1>
+                        // reads it); what is stored is the masked gradient
+                        const float4 ov = bf16x4_to_f32(mkv[j]);
+                        v.x = ov.x > 0.f ? v.x : 0.f; v.y = ov.y > 0.f ? v.y : 0.f;
+                        v.z = ov.z > 0.f ? v.z : 0.f; v.w = ov.w > 0.f ? v.w : 0.f;
+                        *o = v;
+                    } else if (!(DGRAD && a.accumulate && zero)) *o = v;
                     if (bnf) {
                         // same expressions as k_bn_bwd_reduce (bn.hip): the ReLU pattern from the forward's own formula
                         const float4 yv = yvv[j];

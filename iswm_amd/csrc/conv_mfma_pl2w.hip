@@ -250,6 +250,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
     auto epilogue = [&](int tile, int m0, int n0, bool zero) __attribute__((always_inline)) {
         const int mt = tile / a.NT;
         const bool bnf = DGRAD && a.bnf.part != nullptr;
+        const bool mk = bnf && a.bnf.relu == 3;
         if (DGRAD && a.accumulate && zero && !bnf) return;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
 #pragma unroll
             for (int h0 = 0; h0 < RBW; h0 += EH) {
                 float4 oldv[EH], yvv[EH];
+                uint2 mkv[EH];
                 if constexpr (DGRAD) {
 #pragma unroll
                     for (int j = 0; j < EH; ++j) {
@@ -279,9 +281,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
                         const int row = m0 + rb * 16 + lp;
                         oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                         yvv[j] = oldv[j];
+                        mkv[j] = make_uint2(0u, 0u);
                         if (rb < RBW && cok && row < a.M) {
                             if (a.accumulate) oldv[j] = *reinterpret_cast<const float4*>(&a.y[(size_t)row * a.ldy + col]);
                             if (bnf) yvv[j] = *reinterpret_cast<const float4*>(a.bnf.y + (size_t)row * a.bnf.ldy + col);
+                            if (mk) mkv[j] = *reinterpret_cast<const uint2*>(a.bnf.mask + (size_t)row * a.bnf.ldm + col);
                         }
                     }
                 }
@@ -300,7 +304,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
                         } else {
                             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                         }
-                        if (!(DGRAD && a.accumulate && zero)) *o = v;
+                        if (mk) {
+                            // residual producer: pattern from the hi plane of its saved output; the masked gradient is stored
+                            const float4 ov = bf16x4_to_f32(mkv[j]);
+                            v.x = ov.x > 0.f ? v.x : 0.f; v.y = ov.y > 0.f ? v.y : 0.f;
+                            v.z = ov.z > 0.f ? v.z : 0.f; v.w = ov.w > 0.f ? v.w : 0.f;
+                            *o = v;
+                        } else if (!(DGRAD && a.accumulate && zero)) *o = v;
                         if (bnf) {
                             // same expressions as k_bn_bwd_reduce (bn.hip) and k_conv_pl2
                             const float4 yv = yvv[j];

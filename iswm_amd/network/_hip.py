@@ -389,13 +389,22 @@ def _cba_finish(conv, bn, relu, x, y, g, partials, tiles, training, save, residu
     return o, ctx
 
 
+_BN3_FUSE = os.environ.get("ISWM_BN3_FUSE", "1") != "0"      # tuning switch: 0 = residual stages reduce themselves
+
+
 def _bn_stats_request(up):
     """`up` = ctx of the stage that produced this stage's input, when ITS BatchNorm backward is the only consumer of the dx this
     stage returns: the planes data gradient then takes that backward's reduction pass in its epilogue (ops.BnStats)."""
-    if up is None or not ops.planes_on() or up.get("res") or up.get("bn_stats") is not None:
+    if up is None or not ops.planes_on() or up.get("bn_stats") is not None:
         return None
     if ops._relu_code(up["relu"]) not in (0, 1) or not ops._BN_MASK_FROM_Y:
         return None
+    if up.get("res"):
+        # a residual stage (bn3 + identity + ReLU): the pattern is read from its saved output planes and the data gradient
+        # stores dx masked -- see ops.BnStats.mask
+        if not (_BN3_FUSE and ops._relu_code(up["relu"]) == 1 and ops.is_planes(up["out"]) and up["training"]):
+            return None
+        return ops.BnStats(up["y"], up["coef"], up["relu"], mask=up["out"])
     return ops.BnStats(up["y"], up["coef"], up["relu"])
 
 
@@ -410,8 +419,17 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False, 
     dbeta = sink.target(gb) if gb.requires_grad else torch.empty_like(gb)
     # dy goes out pre-split when the data-gradient kernel takes planes (and the conv is not a depthwise one)
     dyp = (not ctx.get("dw")) and ops.planes_conv_ok(conv.cin_p, conv.cout_p, 1)
-    dy, dres = ops.bn_backward(ops.as_f32(dout), o if ctx["relu"] else None, y, ctx["coef"], gw, ctx["relu"], ctx["training"],
-                               dgamma, dbeta, want_dres=ctx["res"], dy_planes=dyp, stats=ctx.pop("bn_stats", None))
+    st = ctx.pop("bn_stats", None)
+    if st is not None and st.partials is not None and st.masked:
+        # dout arrived already masked by this stage's ReLU pattern (the data gradient that produced it applied it and took the
+        # two sums): no activation left to undo, and the residual branch's gradient IS dout
+        dout = ops.as_f32(dout)
+        dy, _ = ops.bn_backward(dout, None, y, ctx["coef"], gw, False, ctx["training"], dgamma, dbeta, want_dres=False,
+                                dy_planes=dyp, stats=st)
+        dres = dout if ctx["res"] else None
+    else:
+        dy, dres = ops.bn_backward(ops.as_f32(dout), o if ctx["relu"] else None, y, ctx["coef"], gw, ctx["relu"], ctx["training"],
+                                   dgamma, dbeta, want_dres=ctx["res"], dy_planes=dyp, stats=st)
     if gw.requires_grad:
         sink.done(gw)
     if gb.requires_grad:

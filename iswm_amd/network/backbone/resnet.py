@@ -58,7 +58,10 @@ class Bottleneck(_hip.HipModule):
         self._saved = (c1, c2, c3, cd) if save else None
         return out
 
-    def bwd(self, dout, sink, need_dx=True):
+    def bwd(self, dout, sink, need_dx=True, up=None):
+        """up: the bn3 stage context of the PREVIOUS block when this block's input gradient is consumed by that stage alone
+        (identity blocks inside a layer): conv1's accumulating data gradient then applies that stage's ReLU pattern and takes
+        its BatchNorm-backward sums (ops.BnStats.mask)"""
         c1, c2, c3, cd = self._saved
         self._saved = None
         # conv3's / conv2's data gradients are consumed by bn2's / bn1's backward alone: they take its reduction pass along
@@ -71,7 +74,7 @@ class Bottleneck(_hip.HipModule):
             dx, _ = _hip.cba_bwd(self.downsample[0], self.downsample[1], cd, dres, sink, dx=dx, accumulate=True)
         else:
             # identity branch: the residual gradient IS dx; conv1's dgrad accumulates into it
-            dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink, dx=dres, accumulate=True)
+            dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink, dx=dres, accumulate=True, up=up)
         return dx
 
     def out_channels_of(self, cin):
@@ -87,8 +90,12 @@ class _Layer(_hip.HipModule, nn.Sequential):
         return x
 
     def bwd(self, dy, sink):
-        for m in reversed(list(self)):
-            dy = m.bwd(dy, sink)
+        blocks = list(self)
+        for i in range(len(blocks) - 1, -1, -1):
+            up = None
+            if i > 0 and blocks[i].downsample is None and blocks[i - 1]._saved is not None:
+                up = blocks[i - 1]._saved[2]            # the previous block's conv3 / bn3 / + identity / ReLU stage
+            dy = blocks[i].bwd(dy, sink, up=up)
         return dy
 
     def out_channels_of(self, cin):

@@ -366,9 +366,13 @@ class BnStats(object):
     (scale, shift, mean, invstd) and `relu` describe the stage that PRODUCED the conv's input (whose BatchNorm backward will
     consume dx); conv2d_dgrad fills `partials`, `tiles` when its kernel supports the fusion (they stay None otherwise)."""
 
-    def __init__(self, y, coef, relu):
+    def __init__(self, y, coef, relu, mask=None):
         self.y, self.coef, self.relu = y, coef, relu
         self.partials, self.tiles = None, 0
+        # a RESIDUAL producer stage (out = relu(bn(y) + identity)): `mask` = its saved output (Planes); the data gradient then
+        # stores dx MASKED by (out > 0) and sets `masked` -- that tensor is the stage's dout (relu already applied) AND the
+        # gradient of its identity branch
+        self.mask, self.masked = mask, False
 
 
 _BN_FUSE = os.environ.get("ISWM_BN_FUSE", "1") != "0"      # tuning switch: 0 = BatchNorm backward always reduces itself
@@ -394,12 +398,16 @@ def conv2d_dgrad(dy, w_ohwi, g, x_like_shape, dx=None, accumulate=False, wpk=Non
                 b = bn_stats
                 tiles = _lib.load().iswm_conv2d_dgrad_pl2_stat_tiles(ctypes.byref(d))
                 part = torch.empty((2, tiles, g.cin), dtype=torch.float64, device=dx.device)
-                masky = _relu_code(b.relu) == 1
+                masky = _relu_code(b.relu) == 1 and b.mask is None
+                pm, ldm, code = None, 0, 2 if masky else 0
+                if b.mask is not None:
+                    pm, _, _, ldm, _ = xrows(b.mask)            # plane 0 = hi
+                    code = 3
                 with _timed(d, 6, g):
                     call("iswm_conv2d_dgrad_pl2_bn", ctypes.byref(d), _p(dy.t), ps, _p(wpk2), _p(dx), int(bool(accumulate)),
                          _p(b.y), rows(b.y)[2], _p(b.coef[2]), _p(b.coef[3]), _p(b.coef[0]) if masky else None,
-                         _p(b.coef[1]) if masky else None, 2 if masky else 0, _p(part), tiles, _stream())
-                b.partials, b.tiles = part, tiles
+                         _p(b.coef[1]) if masky else None, code, _p(pm), ldm, _p(part), tiles, _stream())
+                b.partials, b.tiles, b.masked = part, tiles, b.mask is not None
                 return dx
             with _timed(d, 6, g):
                 call("iswm_conv2d_dgrad_pl2", ctypes.byref(d), _p(dy.t), ps, _p(wpk2), _p(dx), int(bool(accumulate)), _stream())

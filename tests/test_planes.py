@@ -230,6 +230,46 @@ def test_batchnorm_backward_statistics_taken_by_the_data_gradient(monkeypatch):
         assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 2e-5, k
 
 
+def test_residual_stage_backward_taken_by_the_next_blocks_data_gradient(monkeypatch):
+    """bn3 of an identity Bottleneck: the accumulating data gradient of the NEXT block's conv1 applies the stage's ReLU pattern
+    (hi plane of the saved output), stores the masked gradient and takes the two BatchNorm-backward sums
+    (iswm_conv2d_dgrad_pl2_bn relu = 3) -- against the stand-alone reduction pass + materialised residual gradient: same masks,
+    same per-element expressions, so every parameter gradient agrees to summation order.  resnet50 has 12 such blocks."""
+    from iswm_amd import ops
+    from iswm_amd.network import _hip, modeling
+    from oracle.synth import ArchCfg, synth_images, synth_labels, synth_state_dict
+    if not ops.planes_on():
+        pytest.skip("planes are a bf16x6 feature")
+    sd = synth_state_dict(ArchCfg("deeplabv3plus", "resnet50", 2, 16))
+    m = modeling.deeplabv3plus_resnet50(num_classes=2, output_stride=16)
+    m.load_state_dict(sd, strict=True)
+    m.classifier.aspp.project[3].p = 0.0
+    m = m.to(dev()).train()
+    x = synth_images(4, 65, 65, seed=29).to(dev())
+    lab = synth_labels(4, 65, 65, seed=29, p_fg=0.2, p_ignore=0.05).to(dev())
+    w = torch.tensor([1.0, 3.0])
+    codes = []
+    real = ops.call
+
+    def spy(name, *a):
+        if name == "iswm_conv2d_dgrad_pl2_bn":
+            codes.append(a[12])                      # the relu argument
+        return real(name, *a)
+
+    monkeypatch.setattr(ops, "call", spy)
+    lg_a, loss_a, g_a = _step(m, x, lab, w)
+    assert codes.count(3) == 12, codes.count(3)      # layers [3,4,6,3]: 2 + 3 + 5 + 2 identity blocks
+    m.load_state_dict(sd, strict=True)
+    monkeypatch.setattr(_hip, "_BN3_FUSE", False)
+    del codes[:]
+    lg_b, loss_b, g_b = _step(m, x, lab, w)
+    assert codes.count(3) == 0
+    assert torch.equal(lg_a, lg_b) and torch.equal(loss_a, loss_b)
+    for k in g_a:
+        a, b = g_a[k].double().flatten(), g_b[k].double().flatten()
+        assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 2e-5, k
+
+
 def test_stem_stage_vs_reference_golden():
     """stem.npz (generated from the reference's ResNet stem: conv 7x7/2 + BN + ReLU + max-pool on [2,3,65,65]) on the
     GPU: the stage output and the parameter gradients"""
