@@ -13,6 +13,7 @@
 // (slabs summed in a fixed order by k_reduce_slabs: bit-reproducible).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -43,6 +44,13 @@ struct WgArgs {
     unsigned long long* dbg;    // iswm_set_debug_buffer: per-step shader-clock stamps of workgroup 0 (tools/wgrad_timeline.py)
     int vote;                   // 1: skip 32-pixel steps whose gathered pixels are ALL padding (workgroup-wide vote, one more
                                 // barrier per step: only worth it when the filter reaches far -- ASPP rates)
+    // k_wgrad_pls, deep padding: every 256-column tile lies inside ONE filter tap (Cin % 256 == 0), and a tap (dh, dw) only
+    // pairs output pixels of the rectangle [oh0, oh1) x [ow0, ow1) with in-bounds input pixels.  rect = 1: a tile walks
+    // exactly the N x (oh1 - oh0) x (ow1 - ow0) pixels of its tap's rectangle (split nsplit ways) instead of all N x Ho x Wo
+    // with a vote -- no padding pixel is ever fetched or multiplied.  tap_order: taps by descending rectangle size (the heavy
+    // tiles are dispatched first).
+    int rect;
+    unsigned char tap_order[32];
 };
 
 template <int NP>
@@ -553,11 +561,31 @@ __global__ __launch_bounds__(64 * (MW + 4), (MW + 4) / 4) void k_wgrad_pls(const
     const int tiles = a.MT * a.NT;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int split = L / tiles, tile = L - split * tiles;
-    const int mt = tile / a.NT, nt = tile - mt * a.NT;
+    const int mt = tile / a.NT;
+    int nt = tile - mt * a.NT;
+    // rect mode: this tile's tap, its rectangle of output pixels and the part of it this split walks
+    int r_oh0 = 0, r_ow0 = 0, r_h = a.Ho, r_w = a.Wo, r_dh = 0, r_dw = 0;
+    int p_begin = split * a.psplit;
+    int p_end = min(a.P, p_begin + a.psplit);
+    if (a.rect) {
+        const int chunks = a.Cin >> 8;                         // 256-column tiles per tap
+        const int slot = nt / chunks;
+        const int tap = a.tap_order[slot];
+        nt = tap * chunks + (nt - slot * chunks);
+        const int tkh = tap / a.KW, tkw = tap - tkh * a.KW;
+        r_dh = tkh * a.dil - a.pad;
+        r_dw = tkw * a.dil - a.pad;
+        r_oh0 = max(0, -r_dh);
+        r_ow0 = max(0, -r_dw);
+        r_h = max(0, min(a.Ho, a.H - r_dh) - r_oh0);
+        r_w = max(0, min(a.Wo, a.W - r_dw) - r_ow0);
+        const int Pt = a.N * r_h * r_w;
+        const int per = (((Pt + a.nsplit - 1) / a.nsplit) + KS - 1) / KS * KS;
+        p_begin = split * per;
+        p_end = min(Pt, p_begin + per);
+    }
     const int m0 = mt * 128, n0 = nt * 256;
-    const int p_begin = split * a.psplit;
-    const int p_end = min(a.P, p_begin + a.psplit);
-    const int nK = (p_end - p_begin + KS - 1) / KS;
+    const int nK = p_end > p_begin ? (p_end - p_begin + KS - 1) / KS : 0;
 
     if (wave >= MW) {
         // ================= loader =================
@@ -581,25 +609,66 @@ __global__ __launch_bounds__(64 * (MW + 4), (MW + 4) / 4) void k_wgrad_pls(const
             dw[i] = tkw * a.dil - a.pad;
             bbase[i] = reinterpret_cast<const unsigned char*>(a.x) + (size_t)bch * 2;
         }
-        const int HoWo = a.Ho * a.Wo;
-        int pn, poh, pow_;
+        // the pixel grid this tile walks: all of N x Ho x Wo, or (rect) N x r_h x r_w with origin (r_oh0, r_ow0)
+        const int GW_ = max(1, r_w), GHW = max(1, r_h * r_w);
+        int pn, poh, pow_;                                     // image, row and column INSIDE the grid
         {
             const int p = p_begin + kr;
-            pn = p / HoWo;
-            const int rem = p - pn * HoWo;
-            poh = rem / a.Wo;
-            pow_ = rem - poh * a.Wo;
+            pn = p / GHW;
+            const int rem = p - pn * GHW;
+            poh = rem / GW_;
+            pow_ = rem - poh * GW_;
         }
-        const int d_oh = KS / a.Wo, d_ow = KS - d_oh * a.Wo;
-        const bool fast_adv = d_oh + 1 <= a.Ho;
+        const int d_oh = KS / GW_, d_ow = KS - d_oh * GW_;
+        const bool fast_adv = d_oh + 1 <= r_h;
         // DMA of stage kc into its ring slot
         auto issue = [&](int kc) __attribute__((always_inline)) {
             const int p = p_begin + kc * KS + kr;
             const bool pin = p < p_end;
-            const unsigned char* asrc = (pin && aok) ? abase + (size_t)p * a.ldy * 2 : zrow;
-            const long long apst = (pin && aok) ? a.dyps : 0;
+            const unsigned char* asrc;
+            long long apst;
             const unsigned char* bsrc[2];
             long long bpst[2];
+            if (a.rect) {
+                if (kc > 0) {
+                    if (fast_adv) {
+                        int ow = pow_ + d_ow;
+                        const int c1 = ow >= GW_ ? 1 : 0;
+                        pow_ = ow - (c1 ? GW_ : 0);
+                        int oh = poh + d_oh + c1;
+                        const int c2 = oh >= r_h ? 1 : 0;
+                        poh = oh - (c2 ? r_h : 0);
+                        pn += c2;
+                    } else {
+                        pn = p / GHW;
+                        const int rem = p - pn * GHW;
+                        poh = rem / GW_;
+                        pow_ = rem - poh * GW_;
+                    }
+                }
+                const int oh = r_oh0 + poh, ow = r_ow0 + pow_;
+                const bool va = pin && aok;
+                asrc = va ? abase + (size_t)((pn * a.Ho + oh) * a.Wo + ow) * a.ldy * 2 : zrow;
+                apst = va ? a.dyps : 0;
+                const size_t xpix = (size_t)((pn * a.H + oh + r_dh) * a.W + ow + r_dw);      // in bounds by construction
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bool v = pin && bok[i];
+                    bsrc[i] = v ? bbase[i] + xpix * a.ldx * 2 : zrow;
+                    bpst[i] = v ? a.xps : 0;
+                }
+                const unsigned dstr = lds_base + (kc & 3) * STAGE + rg * 1024;
+                if constexpr (ABL & 1) return;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) glds16w(asrc + pl * apst, dstr + pl * PLANE);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) glds16w(bsrc[i] + pl * bpst[i], dstr + (1 + i) * IMG + pl * PLANE);
+                return;
+            }
+            asrc = (pin && aok) ? abase + (size_t)p * a.ldy * 2 : zrow;
+            apst = (pin && aok) ? a.dyps : 0;
             if (a.always) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -611,17 +680,17 @@ __global__ __launch_bounds__(64 * (MW + 4), (MW + 4) / 4) void k_wgrad_pls(const
                 if (kc > 0) {
                     if (fast_adv) {
                         int ow = pow_ + d_ow;
-                        const int c1 = ow >= a.Wo ? 1 : 0;
-                        pow_ = ow - (c1 ? a.Wo : 0);
+                        const int c1 = ow >= GW_ ? 1 : 0;
+                        pow_ = ow - (c1 ? GW_ : 0);
                         int oh = poh + d_oh + c1;
-                        const int c2 = oh >= a.Ho ? 1 : 0;
-                        poh = oh - (c2 ? a.Ho : 0);
+                        const int c2 = oh >= r_h ? 1 : 0;
+                        poh = oh - (c2 ? r_h : 0);
                         pn += c2;
                     } else {
-                        pn = p / HoWo;
-                        const int rem = p - pn * HoWo;
-                        poh = rem / a.Wo;
-                        pow_ = rem - poh * a.Wo;
+                        pn = p / GHW;
+                        const int rem = p - pn * GHW;
+                        poh = rem / GW_;
+                        pow_ = rem - poh * GW_;
                     }
                 }
 #pragma unroll
@@ -738,9 +807,10 @@ __global__ __launch_bounds__(64 * (MW + 4), (MW + 4) / 4) void k_wgrad_pls(const
     }
 #undef ISWM_SB
 
-    // slab / result layout of k_wgrad_plw (k_reduce_slabs_frag): its "wave" w8 = 4 wm + (64-column group), block (mb, nb & 1)
+    // slab / result layout of k_wgrad_plw (k_reduce_slabs_frag): its "wave" w8 = 4 wm + (64-column group), block (mb, nb & 1);
+    // the slab sits at the tile's OUTPUT position (rect mode walks the column tiles in tap_order)
     if (a.nsplit > 1) {
-        float4* slab = reinterpret_cast<float4*>(a.out) + ((size_t)split * tiles + tile) * 8192 + lane;
+        float4* slab = reinterpret_cast<float4*>(a.out) + ((size_t)split * tiles + (mt * a.NT + nt)) * 8192 + lane;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -921,14 +991,40 @@ extern "C" int iswm_conv2d_wgrad_planes_ok(const iswm_conv_desc* d) {
     return (wg_refusal(d) == nullptr && iswm_get_conv_math() >= 1) ? 1 : 0;
 }
 
+// Tap-rectangle mode of k_wgrad_pls (WgArgs::rect): deep padding, stride 1, whole taps per 256-column tile.  Returns the mean
+// number of pixels a tile walks (what the split planner balances) and fills the taps by descending rectangle size.
+static bool wgrad_rect_mode(const iswm_conv_desc* d, int64_t* p_eff, unsigned char* order) {
+    static int on = -1;
+    if (on < 0) on = getenv("ISWM_WG_RECT") ? atoi(getenv("ISWM_WG_RECT")) : 1;
+    const int taps = d->KH * d->KW;
+    if (!on || d->pad < 4 || d->stride != 1 || d->Cin % 256 != 0 || taps <= 1 || taps > 32 || iswm_get_conv_math() != 1) return false;
+    int64_t area[32], sum = 0;
+    for (int t = 0; t < taps; ++t) {
+        const int dh = (t / d->KW) * d->dil - d->pad, dw = (t % d->KW) * d->dil - d->pad;
+        const int h = std::max(0, std::min(d->Ho, d->H - dh) - std::max(0, -dh));
+        const int w = std::max(0, std::min(d->Wo, d->W - dw) - std::max(0, -dw));
+        area[t] = (int64_t)d->N * h * w;
+        sum += area[t];
+    }
+    if (order) {
+        for (int t = 0; t < taps; ++t) order[t] = (unsigned char)t;
+        for (int i = 0; i < taps; ++i)
+            for (int j = i + 1; j < taps; ++j)
+                if (area[order[j]] > area[order[i]]) std::swap(order[i], order[j]);
+    }
+    if (p_eff) *p_eff = std::max<int64_t>(32, sum / taps);
+    return true;
+}
+
 extern "C" size_t iswm_conv2d_wgrad_planes_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
     int ns, ps;
     const int Ktot = d->KH * d->KW * d->Cin;
-    const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+    int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+    wgrad_rect_mode(d, &P, nullptr);                  // the planner balances what the tiles really walk
     plan_wgrad_pl(d->Cout, Ktot, d->KH * d->KW, P, &ns, &ps);
     if (ns <= 1) return 0;
-    if (wgrad_pl_wide(Ktot, d->KH * d->KW, P))      // whole 128 x 256 tiles in accumulator order
+    if (wgrad_pl_wide(Ktot, d->KH * d->KW, (int64_t)d->N * d->Ho * d->Wo))      // whole 128 x 256 tiles in accumulator order
         return (size_t)ns * ((d->Cout + 127) / 128) * ((Ktot + 255) / 256) * 32768 * sizeof(float);
     return (size_t)ns * d->Cout * Ktot * sizeof(float);
 }
@@ -949,7 +1045,9 @@ extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp,
     a.MT = (d->Cout + 127) / 128;
     const int wide = wgrad_pl_wide(a.Ktot, d->KH * d->KW, a.P);
     a.NT = wide ? (a.Ktot + 255) / 256 : (a.Ktot + 127) / 128;
-    plan_wgrad_pl(d->Cout, a.Ktot, d->KH * d->KW, a.P, &a.nsplit, &a.psplit);
+    int64_t p_plan = a.P;
+    a.rect = (wide && wgrad_rect_mode(d, &p_plan, a.tap_order)) ? 1 : 0;
+    plan_wgrad_pl(d->Cout, a.Ktot, d->KH * d->KW, p_plan, &a.nsplit, &a.psplit);
     static int abl = -1;
     if (abl < 0) abl = getenv("ISWM_WG_ABL") ? atoi(getenv("ISWM_WG_ABL")) : 0;
     a.abl = abl;
@@ -958,6 +1056,7 @@ extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp,
         static int fv = -2;
         if (fv == -2) fv = getenv("ISWM_WG_VOTE") ? atoi(getenv("ISWM_WG_VOTE")) : -1;
         a.vote = fv >= 0 ? fv : (d->pad >= 4 ? 1 : 0);
+        if (a.rect) a.vote = 0;                       // nothing to vote on: the tile walks in-bounds pixels only
     }
     a.always = (d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1) ? 1 : 0;
     const size_t need = iswm_conv2d_wgrad_planes_workspace(d);

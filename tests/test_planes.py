@@ -72,6 +72,9 @@ PL_CASES = [
     (1280, 256, 1, 1, 0, 1, 17, 17, 2),
     (128, 200, 3, 2, 1, 1, 23, 19, 5),
     (2048, 256, 1, 1, 0, 1, 1, 1, 4),        # 1x1 spatial
+    (256, 256, 3, 1, 18, 18, 17, 17, 2),     # weight gradient by tap rectangles: only the centre tap has one (17 < 18)
+    (512, 128, 3, 1, 6, 6, 33, 35, 3),       # ... two 256-column tiles per tap, ragged rectangles
+    (256, 256, 5, 1, 8, 4, 21, 19, 2),       # ... 25 taps
 ]
 
 
