@@ -179,6 +179,29 @@ int iswm_bn_backward_stats_pl(const float* dout, int ldd, const void* out, int l
                               float* dbeta, void* dy, int lddy, int64_t dy_ps, float* dres, int lddres,
                               const double* partials, int tiles, void* workspace, size_t workspace_bytes,
                               iswm_stream_t stream);
+/* ---- ASPP as one launch (conv_mfma_pl2t.hip): the parallel branches of network/_deeplab.py:143-172 -- ASPP.convs[0] (1x1),
+ * convs[1..3] (ASPPConv, 3x3 at the three atrous rates, :121-128) -- over ONE tile table.  Rows (pixels) are sorted by their set
+ * of in-bounds filter taps so that a tile runs exactly the taps that reach it; the tiles of all branches are dealt heaviest
+ * first to a persistent grid; the data gradient of the four branches is a single GEMM over their 28 taps (dx written once).
+ * The descriptor gives N, H, W (= Ho, Wo), Cin, Cout (PER BRANCH), stride 1, ldx, ldy; ksize[b] / dil[b] describe branch b
+ * (odd square filter, pad = dil * (k - 1) / 2).  The PLAN (tap table, row order, tile table) is built on the host once per
+ * geometry -- iswm_aspp_plan_bytes / iswm_aspp_plan -- and copied to the device by the caller; kind 0 forward, 1 data
+ * gradient.  Pointer arrays (wpk, y, stats, dw) are host arrays of nbranch device pointers.
+ *   iswm_aspp_fwd : y[b] = conv(x planes, w_b) into fp32 [N*H*W][ldy] + optional BatchNorm partials stats[b] = [2][T][Cout],
+ *                   T = ceil(N*H*W / 144) tile rows of 144 (feed iswm_bn_finalize with tile_rows = 144);
+ *                   wpk[b] = iswm_conv2d_pl2_pack_weights(kind 0) of branch b.
+ *   iswm_aspp_bwd : dx (=|+=) sum_b conv^T(dy_b, w_b); dyp = planes of the concatenated gradient [N*H*W][ld_dy], branch b at
+ *                   channels [b*Cout, (b+1)*Cout); wpk[b] = iswm_conv2d_pl2_pack_weights(kind 1) of branch b.  With xp / dw /
+ *                   workspace it also runs the four weight gradients (iswm_conv2d_wgrad_planes per branch; workspace >= the
+ *                   largest iswm_conv2d_wgrad_planes_workspace of the branches). */
+size_t iswm_aspp_plan_bytes(const iswm_conv_desc* d, int nbranch, const int* ksize, const int* dil, int kind);
+int iswm_aspp_plan(const iswm_conv_desc* d, int nbranch, const int* ksize, const int* dil, int kind, void* host_plan,
+                   int grid_hint);
+int iswm_aspp_fwd(const iswm_conv_desc* d, int nbranch, const int* ksize, const int* dil, const void* plan_dev, const void* xp,
+                  int64_t x_ps, const void* const* wpk, float* const* y, float* const* stats, iswm_stream_t stream);
+int iswm_aspp_bwd(const iswm_conv_desc* d, int nbranch, const int* ksize, const int* dil, const void* plan_dev, const void* dyp,
+                  int64_t dy_ps, int ld_dy, const void* const* wpk, float* dx, int accumulate, const void* xp, int64_t x_ps,
+                  float* const* dw, float* workspace, size_t workspace_bytes, iswm_stream_t stream);
 /* weight gradient with BOTH operands pre-split (x: planes of the conv input, pitch d->ldx; dy: planes of the gradient of
  * the conv output, pitch d->ldy; pitches and plane strides in bf16 elements).  Needs Cin % 8 == 0 and Cout % 8 == 0
  * (iswm_conv2d_wgrad_planes_ok); same result layout, workspace protocol and call sites as iswm_conv2d_wgrad. */

@@ -63,6 +63,12 @@ _SIGS = {
                                          c_int, P]),
     "iswm_bn_backward_stats_pl": (c_int, [P, c_int, P, c_int, c_int64, P, c_int, c_int64, c_int, P, P, P, P, P, c_int, c_int, P, P,
                                           P, c_int, c_int64, P, c_int, P, c_int, P, c_size_t, P]),
+    "iswm_aspp_plan_bytes": (c_size_t, [POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_int), c_int]),
+    "iswm_aspp_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_int), c_int, P, c_int]),
+    "iswm_aspp_fwd": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_int), P, P, c_int64, POINTER(c_void_p),
+                              POINTER(c_void_p), POINTER(c_void_p), P]),
+    "iswm_aspp_bwd": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_int), P, P, c_int64, c_int, POINTER(c_void_p), P,
+                              c_int, P, c_int64, POINTER(c_void_p), P, c_size_t, P]),
     "iswm_conv2d_wgrad_planes_ok": (c_int, [POINTER(ConvDesc)]),
     "iswm_conv2d_wgrad_planes_workspace": (c_size_t, [POINTER(ConvDesc)]),
     "iswm_conv2d_wgrad_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, c_int64, P, P, c_size_t, P]),

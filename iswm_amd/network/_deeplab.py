@@ -13,6 +13,8 @@ MI355X-specific structure:
   * in backward the five branches' input gradients accumulate in place into one
     buffer (dgrad kernels with accumulate=1) instead of five tensors plus four adds.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -107,19 +109,103 @@ class ASPP(_hip.HipModule):
             cat = ops.new_planes(n, h, w, oc * len(self.convs), x.device)
         else:
             cat = ops.new_act(n, h, w, oc * len(self.convs), x.device)
+        fused = self._fwd_fused(x, save, cat, oc)
         for i, conv in enumerate(self.convs):
-            conv.fwd(x, save, out=cat[..., i * oc:(i + 1) * oc])
-        self._saved = (tuple(x.shape), oc) if save else None
+            if fused is None or i >= len(fused):
+                conv.fwd(x, save, out=cat[..., i * oc:(i + 1) * oc])
+        self._saved = (tuple(x.shape), oc, fused) if save else None
         return self.project.fwd(cat, save)
 
+    # ---- the parallel conv branches (convs[0..3]: 1x1 and the three atrous 3x3) as ONE launch each way (ops.aspp_fwd / aspp_dgrad:
+    # rows sorted by in-bounds tap set, one tile table over all branches, the data gradient a single GEMM over the 28 taps)
+    def _branch_convs(self):
+        out = []
+        for m in list(self.convs)[:-1]:
+            st = m._stages() if isinstance(m, _hip.HipSequential) else []
+            if len(st) != 1 or st[0][0] != "cba" or not isinstance(st[0][1], _hip.Conv2d) or not st[0][3] or st[0][3] == 6:
+                return None
+            c = st[0][1]
+            k = c.kernel_size[0]
+            if c.bias is not None or c.stride[0] != 1 or k % 2 == 0 or c.padding[0] != c.dilation[0] * (k - 1) // 2 or c.needs_pack():
+                return None
+            out.append((c, st[0][2]))
+        if not out or any(c.in_channels != out[0][0].in_channels or c.out_channels != out[0][0].out_channels for c, _ in out):
+            return None
+        return out
+
+    def _fwd_fused(self, x, save, cat, oc):
+        """runs the conv branches through ops.aspp_fwd and finishes each (BatchNorm, ReLU into its slice of `cat`); returns the
+        per-branch stage contexts, or None when the fused kernel does not cover this module / input"""
+        if not (ops.planes_on() and ops.is_planes(cat) and x.shape[3] % 64 == 0):
+            return None
+        if not ops.is_planes(x):
+            x = ops.split_planes(x)           # a stand-alone ASPP over an fp32 map (inside the network the backbone hands over planes)
+        br = self._branch_convs()
+        if br is None or len(br) > 4 or br[0][0].out_channels != oc:
+            return None
+        ksize = [c.kernel_size[0] for c, _ in br]
+        dil = [c.dilation[0] for c, _ in br]
+        training = br[0][1].training
+        if any(bn.training != training for _, bn in br):
+            return None
+        wpks = []
+        for c, _ in br:
+            w2 = c.packed2(0)
+            if w2 is None:
+                g = c.geometry(x)
+                d = g.desc(ops.pgeom(x)[4], oc)
+                w2 = torch.empty((ops._pl2_bytes(d, 0) // 4,), dtype=torch.float32, device=x.t.device)
+                ops.call("iswm_conv2d_pl2_pack_weights", ctypes.byref(d), 0, ops._p(c.ohwi()), ops._p(w2), ops._stream())
+            wpks.append(w2)
+        res = ops.aspp_fwd(x, ksize, dil, oc, wpks, training)
+        if res is None:
+            return None
+        ys, parts, tiles = res
+        ctxs = []
+        for i, (c, bn) in enumerate(br):
+            _, ctx = _hip._cba_finish(c, bn, True, x, ys[i], c.geometry(x), parts[i] if parts else None,
+                                      (tiles, ops.ASPP_TILE_ROWS), training, save, None, cat[..., i * oc:(i + 1) * oc], None, False)
+            ctxs.append(ctx)
+        return ctxs
+
     def bwd(self, dy, sink):
-        xshape, oc = self._saved
+        xshape, oc, fused = self._saved
         self._saved = None
         dcat = self.project.bwd(dy, sink)
-        dx = None
+        dx, first = None, 0
+        if fused is not None:
+            dx = self._bwd_fused(dcat, sink, oc, fused, xshape)
+            first = len(fused)
         for i, conv in enumerate(self.convs):
+            if i < first:
+                continue
             d = conv.bwd(dcat[..., i * oc:(i + 1) * oc], sink, True, dx, dx is not None)
             dx = d if dx is None else dx
+        return dx
+
+    def _bwd_fused(self, dcat, sink, oc, ctxs, xshape):
+        br = self._branch_convs()
+        n, h, w, cin = xshape
+        nb = len(ctxs)
+        # the four BatchNorm backwards write their dy (gradient of the raw conv outputs) into ONE planes buffer
+        dyc = ops.new_planes(n, h, w, nb * oc, dcat.device)
+        for i, (c, bn) in enumerate(br):
+            dy_i, _ = _hip.cba_bwd_bn(c, bn, ctxs[i], dcat[..., i * oc:(i + 1) * oc], sink, dy_out=dyc[..., i * oc:(i + 1) * oc])
+            c.write_wgrad(ctxs[i]["x"], dy_i, ctxs[i]["g"], sink)
+        wpks = []
+        for c, _ in br:
+            w2 = c.packed2(1)
+            if w2 is None:
+                g = c.geometry(ctxs[0]["x"])
+                d = g.desc(cin, nb * oc)
+                w2 = torch.empty((ops._pl2_bytes(d, 1) // 4,), dtype=torch.float32, device=dcat.device)
+                ops.call("iswm_conv2d_pl2_pack_weights", ctypes.byref(d), 1, ops._p(c.ohwi()), ops._p(w2), ops._stream())
+            wpks.append(w2)
+        dx = ops.aspp_dgrad(dyc, [c.kernel_size[0] for c, _ in br], [c.dilation[0] for c, _ in br], cin, oc, wpks)
+        if dx is None:                                   # (cannot happen when the forward plan existed; keep the path honest)
+            for i, (c, _) in enumerate(br):
+                dx = ops.conv2d_dgrad(dyc[..., i * oc:(i + 1) * oc], c.ohwi(), ctxs[i]["g"], xshape, dx, dx is not None,
+                                      wpk=c.packed(1), wpk2=c.packed2(1))
         return dx
 
     def out_channels_of(self, cin):

@@ -408,32 +408,41 @@ def _bn_stats_request(up):
     return ops.BnStats(up["y"], up["coef"], up["relu"])
 
 
-def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False, up=None):
-    """Returns (dx, dres): dres is the gradient of the residual input (if any).  up: see _bn_stats_request."""
-    x, y, o, g = ctx["x"], ctx["y"], ctx["out"], ctx["g"]
+def cba_bwd_bn(conv, bn, ctx, dout, sink, dy_out=None):
+    """the BatchNorm (+ activation) backward of a stage: parameter gradients into the sink, returns (dy, dres) with dy the
+    gradient of the raw conv output -- pre-split when the conv's gradient kernels take planes; dy_out: write it there (a Planes
+    slice of a wider buffer: the fused ASPP data gradient reads the four branches' gradients from one tensor)"""
+    y, o = ctx["y"], ctx["out"]
     sep = ctx.get("sep")
     if sep is not None:
         conv = sep.body[1]
     gw, gb = bn.weight, bn.bias
     dgamma = sink.target(gw) if gw.requires_grad else torch.empty_like(gw)
     dbeta = sink.target(gb) if gb.requires_grad else torch.empty_like(gb)
-    # dy goes out pre-split when the data-gradient kernel takes planes (and the conv is not a depthwise one)
     dyp = (not ctx.get("dw")) and ops.planes_conv_ok(conv.cin_p, conv.cout_p, 1)
     st = ctx.pop("bn_stats", None)
     if st is not None and st.partials is not None and st.masked:
-        # dout arrived already masked by this stage's ReLU pattern (the data gradient that produced it applied it and took the
-        # two sums): no activation left to undo, and the residual branch's gradient IS dout
         dout = ops.as_f32(dout)
         dy, _ = ops.bn_backward(dout, None, y, ctx["coef"], gw, False, ctx["training"], dgamma, dbeta, want_dres=False,
-                                dy_planes=dyp, stats=st)
+                                dy=dy_out, dy_planes=dyp, stats=st)
         dres = dout if ctx["res"] else None
     else:
         dy, dres = ops.bn_backward(ops.as_f32(dout), o if ctx["relu"] else None, y, ctx["coef"], gw, ctx["relu"], ctx["training"],
-                                   dgamma, dbeta, want_dres=ctx["res"], dy_planes=dyp, stats=st)
+                                   dgamma, dbeta, want_dres=ctx["res"], dy=dy_out, dy_planes=dyp, stats=st)
     if gw.requires_grad:
         sink.done(gw)
     if gb.requires_grad:
         sink.done(gb)
+    return dy, dres
+
+
+def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False, up=None):
+    """Returns (dx, dres): dres is the gradient of the residual input (if any).  up: see _bn_stats_request."""
+    x, g = ctx["x"], ctx["g"]
+    sep = ctx.get("sep")
+    dy, dres = cba_bwd_bn(conv, bn, ctx, dout, sink)
+    if sep is not None:
+        conv = sep.body[1]
     if ctx.get("dw"):
         return conv.bwd(dy, sink, need_dx, dx, accumulate), dres
     conv.write_wgrad(x, dy, g, sink)

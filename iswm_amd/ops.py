@@ -477,6 +477,124 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
     return dw_ohwi
 
 
+# ---- ASPP: the parallel branch convolutions as one launch (csrc/conv_mfma_pl2t.hip) ---------------------------------
+ASPP_TILE_ROWS = 144
+_ASPP_PLANS = {}
+_ASPP_FUSED = os.environ.get("ISWM_ASPP_FUSED", "1") != "0"      # tuning switch: 0 = one launch per branch
+
+
+def _int_array(v):
+    return (ctypes.c_int * len(v))(*[int(i) for i in v])
+
+
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+def aspp_desc(n, h, w, cin, cout, ldx, ldy):
+    return ConvDesc(n, h, w, cin, h, w, cout, 1, 1, 1, 0, 1, ldx, ldy)
+
+
+def aspp_plan(n, h, w, cin, cout, ksize, dil, kind, device):
+    """device copy of the tile plan of iswm_aspp_fwd (kind 0) / iswm_aspp_bwd (kind 1) for this geometry (built on the host once
+    and cached), or None when the fused kernel does not cover it"""
+    if not (_ASPP_FUSED and planes_on()):
+        return None
+    key = (n, h, w, cin, cout, tuple(ksize), tuple(dil), kind, str(device))
+    plan = _ASPP_PLANS.get(key)
+    if plan is None:
+        lib = _lib.load()
+        d = aspp_desc(n, h, w, cin, cout, cin, cout)
+        ks, dl = _int_array(ksize), _int_array(dil)
+        nb = lib.iswm_aspp_plan_bytes(ctypes.byref(d), len(ksize), ks, dl, kind)
+        if nb == 0:
+            _ASPP_PLANS[key] = False
+            return None
+        host = torch.empty((nb,), dtype=torch.uint8)
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        call("iswm_aspp_plan", ctypes.byref(d), len(ksize), ks, dl, kind, ctypes.c_void_p(host.data_ptr()), cus)
+        plan = _ASPP_PLANS[key] = host.to(device)
+    return None if plan is False else plan
+
+
+def aspp_fwd(x, ksize, dil, cout, wpks, want_stats):
+    """ys[b] = conv(x, w_b) for the parallel branches in one launch; x Planes; wpks[b] packed by iswm_conv2d_pl2_pack_weights
+    (kind 0).  Returns (ys, partials | None, tiles) or None when the geometry is not covered."""
+    _, n, h, w, cin, ldx, ps = xgeom(x)
+    plan = aspp_plan(n, h, w, cin, cout, ksize, dil, 0, x.device)
+    if plan is None:
+        return None
+    nb = len(ksize)
+    tiles = (n * h * w + ASPP_TILE_ROWS - 1) // ASPP_TILE_ROWS
+    ys = [new_act(n, h, w, cout, x.device) for _ in range(nb)]
+    parts = [torch.empty((2, tiles, cout), dtype=torch.float32, device=x.device) for _ in range(nb)] if want_stats else None
+    d = aspp_desc(n, h, w, cin, cout, ldx, cout)
+    gs = [ConvGeom(x, cout, k, k, 1, dl * (k - 1) // 2, dl) for k, dl in zip(ksize, dil)]
+    with _timed_multi("k_conv_pl2t<false>", gs):
+        call("iswm_aspp_fwd", ctypes.byref(d), nb, _int_array(ksize), _int_array(dil), _p(plan), _p(x.t), ps, _ptr_array(wpks),
+             _ptr_array(ys), _ptr_array(parts) if parts else None, _stream())
+    return ys, parts, tiles
+
+
+def aspp_dgrad(dyc, ksize, dil, cin, cout, wpks, dx=None, accumulate=False, x=None, dws=None):
+    """dx (=|+=) sum_b conv^T(dyc[..., b*cout:(b+1)*cout], w_b) in one launch; dyc Planes [N,H,W,nb*cout]; wpks[b] packed by
+    iswm_conv2d_pl2_pack_weights (kind 1).  With x (Planes) and dws (OHWI tensors per branch) the same call also runs the
+    branches' weight gradients (iswm_aspp_bwd's full form).  Returns dx or None when not covered."""
+    _, n, h, w, ctot, ld, ps = xgeom(dyc)
+    nb = len(ksize)
+    assert ctot >= nb * cout
+    plan = aspp_plan(n, h, w, cin, cout, ksize, dil, 1, dyc.device)
+    if plan is None:
+        return None
+    if dx is None:
+        assert not accumulate
+        dx = new_act(n, h, w, cin, dyc.device)
+    d = aspp_desc(n, h, w, cin, cout, geom(dx)[4], cout)
+    gs = []
+    for k, dl in zip(ksize, dil):
+        g = ConvGeom(dx, cout, k, k, 1, dl * (k - 1) // 2, dl)
+        g.alg_cin, g.alg_cout = cin, cout
+        gs.append(g)
+    px, xps, pdw, ws, need = None, 0, None, None, 0
+    if dws is not None:
+        px, xps = x.t, pgeom(x)[5]
+        pdw = _ptr_array(dws)
+        lib = _lib.load()
+        for k, dl in zip(ksize, dil):
+            db = ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, dl * (k - 1) // 2, dl, pgeom(x)[4], ld)
+            need = max(need, lib.iswm_conv2d_wgrad_planes_workspace(ctypes.byref(db)))
+        ws = torch.empty((max(need, 16) // 4,), dtype=torch.float32, device=dyc.device)
+        d = aspp_desc(n, h, w, cin, cout, pgeom(x)[4], cout)
+        assert geom(dx)[4] == pgeom(x)[4], "iswm_aspp_bwd takes ONE pitch for x and dx"
+    with _timed_multi("k_conv_pl2t<true>", gs):
+        call("iswm_aspp_bwd", ctypes.byref(d), nb, _int_array(ksize), _int_array(dil), _p(plan), _p(dyc.t), ps, ld, _ptr_array(wpks),
+             _p(dx), int(bool(accumulate)), _p(px), xps, pdw, _p(ws), need, _stream())
+    return dx
+
+
+class _timed_multi:
+    """_timed for a launch that computes several conv geometries at once (flops add up)"""
+
+    def __init__(self, name, geoms):
+        self.on = KPROF is not None and KPROF.wants(name)
+        self.name, self.geoms = name, geoms
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            g0 = self.geoms[0]
+            tag = "n%d %dx%d c%d->%dx%d aspp d%s" % (g0.n, g0.h, g0.w, g0.alg_cin, len(self.geoms), g0.alg_cout,
+                                                    "/".join(str(g.dil) for g in self.geoms if g.kh > 1))
+            KPROF.add(self.name, self.a, b, sum(g.flops() for g in self.geoms), tag)
+        return False
+
+
 # ---- depthwise conv (groups == channels) -------------------------------------------------------------
 def dwconv2d_fwd(x, w, g, bias=None, out=None):
     """x NHWC [N,H,W,C]; w the parameter [Cw,1,KH,KW] (contiguous), Cw <= C"""

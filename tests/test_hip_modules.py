@@ -312,6 +312,12 @@ def test_train_steps_match_oracle():
     from oracle.optim import OracleSGD
     from oracle.synth import synth_images, synth_labels
     m, cfg, sd = _build("resnet50", 16)
+    # residual branches damped (bn3.weight x 0.3, as oracle/make_golden.py does for its r101 case and for the same reason): with
+    # the synthetic rule's gamma ~ 1 on all 16 residual branches the THREE-step comparison of the stem's update -- the
+    # quantity at the far end of every chain in the graph -- moved between 2.9e-3 and 1.1e-2 under changes of summation
+    # order alone (fused / per-branch ASPP, fused / stand-alone bn3 reduction: profiles/r03_train_steps_sensitivity.txt)
+    sd = {k: (v * 0.3 if k.endswith(".bn3.weight") else v) for k, v in sd.items()}
+    m.load_state_dict(sd, strict=True)
     o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
     lr = 1e-3
     oopt = OracleSGD(o.parameters(), lr=lr)
@@ -347,6 +353,10 @@ def test_train_steps_match_oracle():
             slack = 4 * 1.2e-7 * float(sd[k].abs().max())
             err = max(0.0, float((du_h - du_o).abs().max()) - slack) / float(du_o.abs().max())
             worst_u = max(worst_u, (err, k))
+    import os
+    if os.environ.get("ISWM_TEST_REPORT"):
+        with open(os.environ["ISWM_TEST_REPORT"], "a") as f:
+            f.write("train_steps: worst update err %.4e (%s), worst buffer err %.3e (%s)\n" % (worst_u + worst_b))
     assert worst_b[0] <= RTOL, worst_b
     assert worst_u[0] <= 1e-2, worst_u
     assert int(msd["backbone.bn1.num_batches_tracked"]) == 3

@@ -375,3 +375,53 @@ def test_fused_adam_loads_a_stock_checkpoint_with_stateless_parameters():
     assert float(opt.state[p[1]]["exp_avg"].abs().max()) == 0.0 and int(opt.state[p[1]]["step"]) == 0
     for i, q in enumerate(p):                                        # the state tensors ARE the arena views
         assert opt.state[q]["exp_avg"].data_ptr() == opt.arena.view_of(opt._m, i).data_ptr()
+
+
+def test_aspp_plan_orders_rows_by_tap_set_and_covers_every_tap():
+    """iswm_aspp_plan (host function): the row order of every job is a permutation of the pixels, rows are grouped by their set
+    of in-bounds taps (heaviest first), every tile's tap mask is exactly the union of its rows' sets -- so no in-bounds
+    (pixel, tap) pair is dropped and a uniform tile multiplies no padding -- and the tile table lists every (job, tile) once"""
+    import ctypes
+    import numpy as np
+    from iswm_amd import _lib
+    lib = _lib.load()
+    n, h, w, cin, cout = 3, 33, 35, 128, 256
+    ksize, dil = [1, 3, 3, 3], [1, 6, 12, 18]
+    d = _lib.ConvDesc(n, h, w, cin, h, w, cout, 1, 1, 1, 0, 1, cin, cout)
+    ks, dl = (ctypes.c_int * 4)(*ksize), (ctypes.c_int * 4)(*dil)
+    for kind in (0, 1):
+        nb = lib.iswm_aspp_plan_bytes(ctypes.byref(d), 4, ks, dl, kind)
+        assert nb > 0
+        buf = np.zeros(nb, dtype=np.uint8)
+        assert lib.iswm_aspp_plan(ctypes.byref(d), 4, ks, dl, kind, buf.ctypes.data_as(ctypes.c_void_p), 256) == 0
+        hdr = buf[:72].view(np.int32)                       # struct AsppPlan (csrc/conv_mfma_pl2t.hip): 18 ints, taps[32], jobs[4]
+        magic, kd, nbr, ntaps, njobs, ntiles, N, H, W, M, MT, NT, GC, NC, rm_off, tl_off, total = hdr[:17]
+        assert (kd, nbr, ntaps, N, H, W, M) == (kind, 4, 28, n, h, w, n * h * w) and total == nb
+        assert njobs == (1 if kind else 4) and MT == (M + 143) // 144
+        assert (GC, NC, NT) == ((cout, cin, 1) if kind else (cin, cout, 2))
+        taps = buf[72:72 + 32 * 16].view(np.int32).reshape(32, 4)[:ntaps]          # dh, dw, branch, k32base
+        jobs = buf[72 + 512:72 + 512 + 4 * 32].view(np.int32).reshape(4, 8)[:njobs]  # tap_begin, ntaps, branch, rowmap_off
+        rowmap = buf[rm_off:rm_off + njobs * M * 4].view(np.int32).reshape(njobs, M)
+        tiles = buf[tl_off:tl_off + ntiles * 16].view(np.int32).reshape(ntiles, 4)   # job, mt, nt, mask
+        assert ntiles == njobs * MT * NT
+        assert len({tuple(t[:3]) for t in tiles.tolist()}) == ntiles                   # every (job, mt, nt) once
+        pop = np.array([bin(int(m) & 0xFFFFFFFF).count("1") for m in tiles[:, 3]])
+        assert pop[0] == pop.max() and pop[:min(256, ntiles)].min() >= pop[min(256, ntiles):2 * 256].max(initial=0) - 0  # heaviest band first
+        for j in range(njobs):
+            tb, nt_ = int(jobs[j, 0]), int(jobs[j, 1])
+            code = rowmap[j]
+            pn, ph, pw = code >> 20, (code >> 10) & 1023, code & 1023
+            assert len(np.unique(code)) == M and pn.max() == n - 1 and ph.max() == h - 1 and pw.max() == w - 1
+            mask = np.zeros(M, dtype=np.int64)
+            for t in range(nt_):
+                ok = (ph + taps[tb + t, 0] >= 0) & (ph + taps[tb + t, 0] < h) & (pw + taps[tb + t, 1] >= 0) & (pw + taps[tb + t, 1] < w)
+                mask |= ok.astype(np.int64) << t
+            cnt = np.array([bin(int(m)).count("1") for m in mask])
+            assert (np.diff(cnt) <= 0).all()                                           # heaviest tap sets first
+            assert len(np.unique(mask)) == len(np.unique(mask[np.r_[True, np.diff(mask) != 0]]))   # equal sets are contiguous
+            for tl in tiles[tiles[:, 0] == j]:
+                rows = mask[tl[1] * 144:(tl[1] + 1) * 144]
+                assert int(np.bitwise_or.reduce(rows)) == int(tl[3]) & 0xFFFFFFFF
+    # geometries the fused kernel does not take answer 0 bytes (callers fall back to one launch per branch)
+    bad = _lib.ConvDesc(n, h, w, 100, h, w, cout, 1, 1, 1, 0, 1, 100, cout)
+    assert lib.iswm_aspp_plan_bytes(ctypes.byref(bad), 4, ks, dl, 0) == 0

@@ -273,6 +273,51 @@ def test_residual_stage_backward_taken_by_the_next_blocks_data_gradient(monkeypa
         assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 2e-5, k
 
 
+@pytest.mark.parametrize("n,h,w", [(6, 6, 6), (3, 17, 19), (2, 33, 33)])
+def test_aspp_module_fused_vs_per_branch(monkeypatch, n, h, w):
+    """the ASPP module (network/_deeplab.py:143-172) with its conv branches through iswm_aspp_fwd / iswm_aspp_bwd against the same
+    module running one launch per branch: output, input gradient, every parameter gradient and the BatchNorm buffers"""
+    from iswm_amd import ops
+    from iswm_amd.network import _deeplab, _hip
+    if not ops.planes_on():
+        pytest.skip("planes are a bf16x6 feature")
+    torch.manual_seed(5)
+    m = _deeplab.ASPP(256, [6, 12, 18]).to(dev()).train()
+    m.project[3].p = 0.0
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = rnd(n, h, w, 256, seed=31).to(dev())
+    up = rnd(n, h, w, 256, seed=32).to(dev())
+    calls = []
+    real = ops.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(ops, "call", spy)
+
+    def run():
+        m.load_state_dict(sd)
+        for p in m.parameters():
+            p.grad = None
+        y = m.fwd(ops.split_planes(x), True)
+        dx = m.bwd(up, _hip.GradSink())
+        return (ops.as_f32(y).clone(), ops.as_f32(dx).clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+
+    ya, dxa, ga, ba = run()
+    assert calls.count("iswm_aspp_fwd") == 1 and calls.count("iswm_aspp_bwd") == 1
+    monkeypatch.setattr(ops, "_ASPP_FUSED", False)
+    del calls[:]
+    yb, dxb, gb, bb = run()
+    assert calls.count("iswm_aspp_fwd") == 0
+    assert rel_err(ya, yb) <= 2e-5 and rel_err(dxa, dxb) <= 2e-5
+    for k in ga:
+        assert rel_err(ga[k], gb[k]) <= 5e-5, k
+    for k in ba:
+        assert rel_err(ba[k], bb[k]) <= 2e-5, k
+
+
 def test_stem_stage_vs_reference_golden():
     """stem.npz (generated from the reference's ResNet stem: conv 7x7/2 + BN + ReLU + max-pool on [2,3,65,65]) on the
     GPU: the stage output and the parameter gradients"""
