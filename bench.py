@@ -38,7 +38,7 @@ X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 # wide-read correction of the MI355X guide), aggregated by tools/pmc_aggregate.py into profiles/.  The table records a
 # hash of the kernel sources it was measured on: `traffic` is reported only when that hash matches the sources of the
 # build being timed; otherwise it is null and the stale figure is returned under its own name.
-PMC_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc", "step_traffic.json")
+PMC_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc", "step_traffic.json")
 
 
 def csrc_hash():

@@ -829,7 +829,7 @@ static PatchArgs patch_args(const iswm_conv_desc* d, bool dgrad, int PH, int PW)
     return p;
 }
 
-namespace iswm { int wgrad_pl_is_wide(const iswm_conv_desc* d); }
+namespace iswm { int wgrad_pl_is_wide(const iswm_conv_desc* d); int wgrad_pl_kernel_kind(const iswm_conv_desc* d); }
 
 // may this geometry run the 256-column planes kernel (conv_mfma_pl2w.hip)?  bf16x6 only; strided data gradients keep the
 // parity-ordered rows of k_conv_pl2
@@ -842,7 +842,8 @@ static int pl2_K(const iswm_conv_desc* d, bool dgrad) { return d->KH * d->KW * (
 extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* buf, int buflen) {
     ISWM_REQUIRE(d && buf && buflen > 0 && kind >= 0 && kind <= 7, "kernel_name: bad argument");
     if (kind == 7) {   // iswm_conv2d_wgrad_planes
-        snprintf(buf, buflen, wgrad_pl_is_wide(d) ? "k_wgrad_plw<%d, false, 0>" : "k_wgrad_pl<%d>", math_planes());
+        const int kk = wgrad_pl_kernel_kind(d);
+        snprintf(buf, buflen, kk == 2 ? "k_wgrad_pls<%d, 0, 4>" : kk == 1 ? "k_wgrad_plw<%d, false, 0>" : "k_wgrad_pl<%d>", math_planes());
         return 0;
     }
     if (kind >= 5) {   // 5 / 6: iswm_conv2d_fwd_pl2 / iswm_conv2d_dgrad_pl2

@@ -1016,6 +1016,19 @@ static bool wgrad_rect_mode(const iswm_conv_desc* d, int64_t* p_eff, unsigned ch
     return true;
 }
 
+// which kernel iswm_conv2d_wgrad_planes launches for this geometry (iswm_conv2d_kernel_name): 0 k_wgrad_pl (128 x 128 tiles),
+// 1 k_wgrad_plw (128 x 256, all waves load and multiply, culling vote), 2 k_wgrad_pls (loader / multiplier waves)
+namespace iswm {
+int wgrad_pl_kernel_kind(const iswm_conv_desc* d) {
+    if (!wgrad_pl_is_wide(d)) return 0;
+    static int spec = -1;
+    if (spec < 0) spec = getenv("ISWM_WG_SPEC") ? atoi(getenv("ISWM_WG_SPEC")) : 1;
+    const bool rect = wgrad_rect_mode(d, nullptr, nullptr);
+    const bool vote = d->pad >= 4 && !rect;
+    return (spec && !vote) ? 2 : 1;
+}
+}  // namespace iswm
+
 extern "C" size_t iswm_conv2d_wgrad_planes_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
     int ns, ps;
