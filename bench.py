@@ -355,7 +355,7 @@ def main():
                              else "BASELINE.json configs[1]",
                              {"bf16x6": "six bf16 MFMAs on an exact 3-way operand split (bf16x6, fp32-level error)",
                               "f32": "v_mfma_f32_32x32x2_f32",
-                              "bf16": "ONE bf16 MFMA on operands rounded to bf16 (mixed precision, NOT fp32-grade)"}[math_name]),
+                              "bf16": "ONE bf16 MFMA on bf16-stored activations (mixed precision, NOT fp32-grade)"}[math_name]),
                 "conv_math": math_name,
                 "global_batch": B * world,
                 "parallelism": "dp%d" % world,
@@ -428,8 +428,11 @@ def main():
             lib.iswm_set_conv_math(1)
             out["alt_conv_math_bf16"] = {"value": round(B / dt2, 3), "unit": "images/sec",
                                          "ms_per_step": round(dt2 * 1e3, 3),
-                                         "note": "identical step with bf16-rounded MFMA inputs, fp32 accumulate / storage "
-                                                 "(ISWM_CONV_MATH=bf16): mixed precision, NOT the headline arithmetic"}
+                                         "note": "identical step in mixed precision (ISWM_CONV_MATH=bf16, BASELINE configs[4]): "
+                                                 "activations between convolutions stored as ONE bf16 plane, one bf16 MFMA per "
+                                                 "product, fp32 accumulation / BatchNorm statistics / master weights / loss.  "
+                                                 "Reduced precision: NOT the headline arithmetic; parity unpinned (the reference "
+                                                 "has no such mode; checked against a same-rounding oracle)"}
         if world == 1 and args.torch_baseline:
             del model, net, opt, images, labels          # free the product's activations / arenas first
             torch.cuda.empty_cache()

@@ -1198,7 +1198,8 @@ extern "C" int iswm_conv2d_fwd_pl2(const iswm_conv_desc* d, const void* xp, int6
     if (int e = validate(d)) return e;
     ISWM_REQUIRE(xp && wpk && y, "conv_fwd_pl2: null pointer");
     ISWM_REQUIRE(aligned16(xp) && aligned16(wpk) && aligned16(y), "conv_fwd_pl2: pointers must be 16-byte aligned");
-    ISWM_REQUIRE(d->Cin % 64 == 0 && d->ldx % 8 == 0 && plane_stride % 8 == 0, "conv_fwd_pl2: Cin %% 64, ldx %% 8, plane stride %% 8");
+    ISWM_REQUIRE(d->Cin % 64 == 0 && d->ldx % 8 == 0 && (plane_stride % 8 == 0 || (plane_stride == -1 && math_planes() == 1)),
+                 "conv_fwd_pl2: Cin %% 64, ldx %% 8, plane stride %% 8 (or -1: one rounded plane under conv math bf16)");
     ConvArgs a = base_args(d);
     a.x = reinterpret_cast<const float*>(xp); a.w = reinterpret_cast<const float*>(wpk); a.bias = bias; a.y = y;
     a.stats = stat_partials;
@@ -1218,7 +1219,8 @@ static int dgrad_pl2_impl(const iswm_conv_desc* d, const void* dyp, int64_t plan
     if (int e = validate(d)) return e;
     ISWM_REQUIRE(dyp && wpk && dx, "conv_dgrad_pl2: null pointer");
     ISWM_REQUIRE(aligned16(dyp) && aligned16(wpk) && aligned16(dx), "conv_dgrad_pl2: pointers must be 16-byte aligned");
-    ISWM_REQUIRE(d->Cout % 64 == 0 && d->ldy % 8 == 0 && plane_stride % 8 == 0, "conv_dgrad_pl2: Cout %% 64, ldy %% 8, plane stride %% 8");
+    ISWM_REQUIRE(d->Cout % 64 == 0 && d->ldy % 8 == 0 && (plane_stride % 8 == 0 || (plane_stride == -1 && math_planes() == 1)),
+                 "conv_dgrad_pl2: Cout %% 64, ldy %% 8, plane stride %% 8 (or -1: one rounded plane under conv math bf16)");
     ConvArgs a = base_args(d);
     a.x = reinterpret_cast<const float*>(dyp); a.w = reinterpret_cast<const float*>(wpk); a.y = dx; a.accumulate = accumulate;
     a.ldx = d->ldy; a.ldy = d->ldx;

@@ -646,6 +646,25 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
     a.NT = narrow ? 1 : (nc + 127) / 128;
     const int tiles = a.MT * a.NT;
     dim3 grid(tiles < ncu ? tiles : ncu), blk(512);
+    if (planes == 1) {          // ONE bf16 plane per operand (conv math "bf16": activations stored rounded, one MFMA per product)
+#define PL2_LAUNCH1(R, W)                                                                      \
+    do {                                                                                       \
+        if (dgrad) hipLaunchKernelGGL((k_conv_pl2<R, W, 1, true>), grid, blk, 0, s, a);         \
+        else hipLaunchKernelGGL((k_conv_pl2<R, W, 1, false>), grid, blk, 0, s, a);              \
+    } while (0)
+        if (narrow) {
+            if (rbw == 8) PL2_LAUNCH1(4, 2);
+            else if (rbw == 10) PL2_LAUNCH1(5, 2);
+            else return false;
+        } else {
+            if (rbw == 8) PL2_LAUNCH1(8, 1);
+            else if (rbw == 9) PL2_LAUNCH1(9, 1);
+            else if (rbw == 10) PL2_LAUNCH1(10, 1);
+            else return false;
+        }
+#undef PL2_LAUNCH1
+        return true;
+    }
     if (planes != 3) return false;
 #define PL2_LAUNCH(R, W)                                                                       \
     do {                                                                                       \

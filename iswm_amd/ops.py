@@ -60,19 +60,34 @@ _PLANES_ENV = os.environ.get("ISWM_PLANES", "1") != "0"
 _WGRAD_PLANES = os.environ.get("ISWM_WGRAD_PLANES", "1") != "0"     # tuning switch: 0 joins the planes and runs the fp32-input weight gradient
 
 
+# conv math "bf16" (BASELINE configs[4], mixed precision): activations between convolutions are STORED as one bf16 plane
+# (round to nearest even) -- 2 bytes per element through every memory-bound pass instead of 4 (fp32) or 6 (bf16x6 planes).
+# ISWM_BF16_STORE=0 keeps them fp32 and rounds inside the conv kernels (the round-2 form of this mode).
+_BF16_STORE = os.environ.get("ISWM_BF16_STORE", "1") != "0"
+
+
+def nplanes():
+    """bf16 planes an activation is stored as under the current conv math: 3 (bf16x6: exact split), 1 (bf16: rounded), 0 (fp32)"""
+    math = _lib.load().iswm_get_conv_math()
+    if not _PLANES_ENV:
+        return 0
+    return 3 if math == 1 else (1 if (math == 2 and _BF16_STORE) else 0)
+
+
 def planes_on():
-    return _PLANES_ENV and _lib.load().iswm_get_conv_math() == 1
+    return nplanes() > 0
 
 
 class Planes(object):
     """An NHWC fp32 activation held as its exact 3-way bf16 split: `t` is a bf16 tensor [3, N, H, W, C]
     (plane, then a pitched NHWC view), hi + mid + lo == the fp32 value bit for bit.  Producers (BatchNorm / pooling /
-    resize passes) write it, the convolution kernels stage it into LDS by DMA; anything else asks for `.f32()`."""
+    resize passes) write it, the convolution kernels stage it into LDS by DMA; anything else asks for `.f32()`.
+    Under conv math "bf16" there is ONE plane, [1, N, H, W, C]: the value rounded to nearest bf16 (C-ABI plane stride -1)."""
 
     __slots__ = ("t",)
 
     def __init__(self, t):
-        assert t.dim() == 5 and t.dtype == torch.bfloat16 and t.shape[0] == 3
+        assert t.dim() == 5 and t.dtype == torch.bfloat16 and t.shape[0] in (1, 3)
         self.t = t
 
     @property
@@ -112,13 +127,13 @@ def as_f32(x):
 
 def new_planes(n, h, w, c, device, zero=False):
     mk = torch.zeros if zero else torch.empty
-    return Planes(mk((3, n, h, w, c), dtype=torch.bfloat16, device=device))
+    return Planes(mk((max(1, nplanes()), n, h, w, c), dtype=torch.bfloat16, device=device))
 
 
 def pgeom(x):
     """(N, H, W, C, ld, plane stride) of a Planes tensor, both in bf16 elements"""
     n, h, w, c, ld = geom(x.t[0], torch.bfloat16)
-    return n, h, w, c, ld, x.t.stride(0)
+    return n, h, w, c, ld, (x.t.stride(0) if x.t.shape[0] == 3 else -1)
 
 
 def xgeom(x):
@@ -134,7 +149,7 @@ def split_planes(x, out=None):
     if out is None:
         out = new_planes(n, h, w, c, x.device)
     _, _, _, _, ldp, ps = pgeom(out)
-    call("iswm_split_planes", _p(x), n * h * w, c, ld, _p(out.t), ldp, ps, _stream())
+    call("iswm_split_planes", _p(x), n * h * w, c, ld, _p(out.t), ldp, ps if ps > 0 else n * h * w * ldp, _stream())
     return out
 
 

@@ -32,6 +32,10 @@ class OracleDeepLab:
             self.sd[k] = t
         self.training = False
         self.conv_math = "f32"      # "bf16": see _conv
+        # act_bf16 (with conv_math "bf16"): the product's mixed-precision mode STORES the activations that feed convolutions as
+        # one bf16 plane (round to nearest even); the restatement rounds at the same points -- every stage output that the
+        # product writes as planes (_store) -- with a straight-through gradient, as the hand-written backward has
+        self.act_bf16 = False
         self.dropout_p = dropout_p  # nn.Dropout(0.1), network/_deeplab.py:165
         # Optional {site: bool NCHW mask}: when given, every ReLU uses the SUPPLIED sign pattern
         # (z * mask) instead of its own (z > 0).  Tests pass the HIP path's masks here so that
@@ -63,13 +67,22 @@ class OracleDeepLab:
             p.grad = None
 
     # -- building blocks ----------------------------------------------------------
-    def _relu(self, z, site):
-        """nn.ReLU at the site named by the BatchNorm that feeds it."""
+    def _store(self, t, force=False):
+        """an activation the product keeps pre-split for a consumer conv: 64-aligned channel counts (or a slice of a wider
+        planes buffer: force) are rounded to bf16 under act_bf16; identity otherwise"""
+        if not (self.act_bf16 and self.conv_math == "bf16") or not (force or t.shape[1] % 64 == 0):
+            return t
+        return t + (t.bfloat16().to(t.dtype) - t).detach()
+
+    def _relu(self, z, site, store=True, force=False):
+        """nn.ReLU at the site named by the BatchNorm that feeds it (store: the product writes this output as planes)."""
         if self.preact is not None:
             self.preact[site] = z.detach()
         if self.relu_masks is not None:
-            return z * self.relu_masks[site].to(z.dtype)
-        return F.relu(z)
+            a = z * self.relu_masks[site].to(z.dtype)
+        else:
+            a = F.relu(z)
+        return self._store(a, force) if store else a
 
     def _bn(self, x, prefix):
         """nn.BatchNorm2d train/eval incl. running-stat update (unbiased var,
@@ -111,8 +124,8 @@ class OracleDeepLab:
         """IntermediateLayerGetter.forward over the ResNet children
         (network/utils.py:78-93, network/backbone/resnet.py:144-155)."""
         x = self._conv(x, "backbone.conv1.weight", 2, 3)
-        x = self._relu(self._bn(x, "backbone.bn1"), "backbone.bn1")
-        x = F.max_pool2d(x, 3, 2, 1)
+        x = self._relu(self._bn(x, "backbone.bn1"), "backbone.bn1", store=False)
+        x = self._store(F.max_pool2d(x, 3, 2, 1))
         feats = OrderedDict()
         for li, L in enumerate(self.cfg.layers()):
             for bi, d in enumerate(L["dils"]):
@@ -133,10 +146,10 @@ class OracleDeepLab:
             res.append(self._relu(self._bn(y, ap + ".convs.%d.1" % i), ap + ".convs.%d.1" % i))
         size = x.shape[-2:]
         p = F.adaptive_avg_pool2d(x, 1)
-        p = self._relu(self._bn(self._conv(p, ap + ".convs.4.1.weight"), ap + ".convs.4.2"), ap + ".convs.4.2")
-        res.append(F.interpolate(p, size=size, mode="bilinear", align_corners=False))
+        p = self._relu(self._bn(self._conv(p, ap + ".convs.4.1.weight"), ap + ".convs.4.2"), ap + ".convs.4.2", store=False)
+        res.append(self._store(F.interpolate(p, size=size, mode="bilinear", align_corners=False)))
         y = torch.cat(res, dim=1)
-        y = self._relu(self._bn(self._conv(y, ap + ".project.0.weight"), ap + ".project.1"), ap + ".project.1")
+        y = self._relu(self._bn(self._conv(y, ap + ".project.0.weight"), ap + ".project.1"), ap + ".project.1", store=False)
         return F.dropout(y, self.dropout_p, self.training)
 
     def head(self, feats):
@@ -144,9 +157,9 @@ class OracleDeepLab:
         if self.cfg.name == "deeplabv3plus":
             # DeepLabHeadV3Plus.forward, network/_deeplab.py:55-61
             low = self._relu(self._bn(self._conv(feats["low_level"], c + ".project.0.weight"),
-                                      c + ".project.1"), c + ".project.1")
+                                      c + ".project.1"), c + ".project.1", force=True)      # a slice of the 320-wide planes buffer
             y = self.aspp(feats["out"], c + ".aspp")
-            y = F.interpolate(y, size=low.shape[2:], mode="bilinear", align_corners=False)
+            y = self._store(F.interpolate(y, size=low.shape[2:], mode="bilinear", align_corners=False))
             y = torch.cat([low, y], dim=1)
             y = self._relu(self._bn(self._conv(y, c + ".classifier.0.weight", 1, 1), c + ".classifier.1"), c + ".classifier.1")
             y = self._relu(self._bn(self._conv(y, c + ".classifier.3.weight", 1, 1), c + ".classifier.4"), c + ".classifier.4")
