@@ -110,7 +110,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2t(const AsppArgs a) {
     const unsigned char* zrow = reinterpret_cast<const unsigned char*>(g_zero_row_pl2t) + gs * 16;
 
     // ---- issue side
-    int i_tile = blockIdx.x;
+    // workgroups b and b + 8 share an XCD: give every XCD a contiguous run of table entries -- the column tiles of one row
+    // tile (adjacent entries: same activation rows) then share one L2 instead of being dealt across the eight
+    int i_tile = xcd_remap(blockIdx.x, gridDim.x);
     int i_job = 0, i_mt = 0, i_m0 = 0, i_n0 = 0;
     unsigned i_mask = 0;                 // taps of the tile still to run
     int ihb[NRG], iwb[NRG], pb[NRG];

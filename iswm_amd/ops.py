@@ -513,7 +513,7 @@ def aspp_desc(n, h, w, cin, cout, ldx, ldy):
 def aspp_plan(n, h, w, cin, cout, ksize, dil, kind, device):
     """device copy of the tile plan of iswm_aspp_fwd (kind 0) / iswm_aspp_bwd (kind 1) for this geometry (built on the host once
     and cached), or None when the fused kernel does not cover it"""
-    if not (_ASPP_FUSED and planes_on()):
+    if not (_ASPP_FUSED and nplanes() == 3):          # bf16x6 only (checked per call: the conv math can change at run time)
         return None
     key = (n, h, w, cin, cout, tuple(ksize), tuple(dil), kind, str(device))
     plan = _ASPP_PLANS.get(key)
