@@ -26,6 +26,7 @@
 namespace iswm {
 
 static __device__ __attribute__((aligned(128))) unsigned short g_zero_row_pl2[64];   // 128 B of zeros
+static __device__ float4 g_dump_pl2[64];         // where the epilogue's out-of-range lanes store (never read)
 
 typedef __attribute__((address_space(3))) void* lds_vptr2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -320,26 +321,51 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         // statistics) is fetched for all row blocks before the first store: hipcc cannot move a load above a store that
         // may alias it, and one load-then-store per row block costs a memory round trip per block
         // (in two halves of the row blocks: 2 x RBW x 4 more live registers do not fit beside the RBW = 10 accumulators)
+        // BRANCH-FREE on purpose.  With a predicate around each store (`if (cok && row < M) *o = v`) hipcc gives every store a
+        // basic block of its own, and its waitcnt pass -- conservative at the joins -- then puts `s_waitcnt vmcnt(0)` in front of
+        // EVERY store of the main-loop epilogue (the bias / old-gradient loads it must wait for are younger than the next
+        // stage's weight loads).  Stores count in vmcnt, so each store waited for the previous one to be acknowledged: 9
+        // serial write round trips per tile, ~3 us -- a third of a K = 256 tile.  Out-of-range lanes now read a zero line and
+        // store into a per-lane dump slot instead, selected by address: one block, one wait, back-to-back stores.
+        const float4* const zero4 = reinterpret_cast<const float4*>(g_zero_row_pl2);
+        const uint2* const zero2 = reinterpret_cast<const uint2*>(g_zero_row_pl2);
+        float4* const dump = g_dump_pl2 + lane;
+        const bool acc_old = DGRAD && a.accumulate;
+        const bool relu2 = bnf && a.bnf.relu == 2;
         constexpr int EH = (RBW + 1) / 2;
 #pragma unroll
         for (int h0 = 0; h0 < RBW; h0 += EH) {
             float4 oldv[EH], yvv[EH];
             uint2 mkv[EH];
             if constexpr (DGRAD) {
+                // each kind of read under ONE uniform branch per batch (a plain data gradient issues none of them)
+                int pixj[EH];
+                bool okj[EH];
 #pragma unroll
                 for (int j = 0; j < EH; ++j) {
                     const int rb = h0 + j;
                     const int lrw = (wm * RBW + rb) * 16 + lp;
                     const int row = m0 + lrw;
+                    okj[j] = rb < RBW && cok && row < a.M;
+                    pixj[j] = okj[j] ? (par ? rowpix[lrw] : row) : 0;
                     oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     yvv[j] = oldv[j];
                     mkv[j] = make_uint2(0u, 0u);
-                    if (rb < RBW && cok && row < a.M) {
-                        const int pix = par ? rowpix[lrw] : row;
-                        if (a.accumulate) oldv[j] = *reinterpret_cast<const float4*>(&a.y[(size_t)pix * a.ldy + col]);
-                        if (bnf) yvv[j] = *reinterpret_cast<const float4*>(a.bnf.y + (size_t)pix * a.bnf.ldy + col);
-                        if (mk) mkv[j] = *reinterpret_cast<const uint2*>(a.bnf.mask + (size_t)pix * a.bnf.ldm + col);
-                    }
+                }
+                if (acc_old) {
+#pragma unroll
+                    for (int j = 0; j < EH; ++j)
+                        oldv[j] = *(okj[j] ? reinterpret_cast<const float4*>(&a.y[(size_t)pixj[j] * a.ldy + col]) : zero4);
+                }
+                if (bnf) {
+#pragma unroll
+                    for (int j = 0; j < EH; ++j)
+                        yvv[j] = *(okj[j] ? reinterpret_cast<const float4*>(a.bnf.y + (size_t)pixj[j] * a.bnf.ldy + col) : zero4);
+                }
+                if (mk) {
+#pragma unroll
+                    for (int j = 0; j < EH; ++j)
+                        mkv[j] = *(okj[j] ? reinterpret_cast<const uint2*>(a.bnf.mask + (size_t)pixj[j] * a.bnf.ldm + col) : zero2);
                 }
             }
 #pragma unroll
@@ -348,38 +374,37 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
                 if (rb >= RBW) continue;
                 const int lrw = (wm * RBW + rb) * 16 + lp;
                 const int row = m0 + lrw;
-                if (cok && row < a.M) {
-                    const int pix = (DGRAD && par) ? rowpix[DGRAD ? lrw : 0] : row;
-                    float4* o = reinterpret_cast<float4*>(&a.y[(size_t)pix * a.ldy + col]);
-                    float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
-                    if (DGRAD && a.accumulate) {
-                        const float4 old = oldv[j];
-                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-                    } else {
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    }
-                    if (mk) {
-                        // residual producer: the pattern comes from the hi plane of its saved output (as k_bn_bwd_reduce<1>
-                        // reads it); what is stored is the masked gradient
-                        const float4 ov = bf16x4_to_f32(mkv[j]);
-                        v.x = ov.x > 0.f ? v.x : 0.f; v.y = ov.y > 0.f ? v.y : 0.f;
-                        v.z = ov.z > 0.f ? v.z : 0.f; v.w = ov.w > 0.f ? v.w : 0.f;
-                        *o = v;
-                    } else if (!(DGRAD && a.accumulate && zero)) *o = v;
-                    if (bnf) {
-                        // same expressions as k_bn_bwd_reduce (bn.hip): the ReLU pattern from the forward's own formula
-                        const float4 yv = yvv[j];
-                        float4 g = v;
-                        if (a.bnf.relu == 2) {
-                            g.x = (yv.x - f_mu.x) * f_sc.x + f_sh.x > 0.f ? g.x : 0.f;
-                            g.y = (yv.y - f_mu.y) * f_sc.y + f_sh.y > 0.f ? g.y : 0.f;
-                            g.z = (yv.z - f_mu.z) * f_sc.z + f_sh.z > 0.f ? g.z : 0.f;
-                            g.w = (yv.w - f_mu.w) * f_sc.w + f_sh.w > 0.f ? g.w : 0.f;
-                        }
-                        fs[0] += g.x; fs[1] += g.y; fs[2] += g.z; fs[3] += g.w;
-                        fq[0] += g.x * ((yv.x - f_mu.x) * f_is.x); fq[1] += g.y * ((yv.y - f_mu.y) * f_is.y);
-                        fq[2] += g.z * ((yv.z - f_mu.z) * f_is.z); fq[3] += g.w * ((yv.w - f_mu.w) * f_is.w);
-                    }
+                const bool ok = cok && row < a.M;
+                const int pix = ok ? ((DGRAD && par) ? rowpix[DGRAD ? lrw : 0] : row) : 0;
+                float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+                float4 addv = bv;
+                if constexpr (DGRAD) {
+                    addv.x = acc_old ? oldv[j].x : bv.x; addv.y = acc_old ? oldv[j].y : bv.y;
+                    addv.z = acc_old ? oldv[j].z : bv.z; addv.w = acc_old ? oldv[j].w : bv.w;
+                }
+                v.x += addv.x; v.y += addv.y; v.z += addv.z; v.w += addv.w;
+                if constexpr (DGRAD) {
+                    // residual producer (mk): the pattern comes from the hi plane of its saved output (as k_bn_bwd_reduce<1> reads
+                    // it); what is stored is the masked gradient
+                    const float4 ov = bf16x4_to_f32(mkv[j]);
+                    v.x = (!mk || ov.x > 0.f) ? v.x : 0.f; v.y = (!mk || ov.y > 0.f) ? v.y : 0.f;
+                    v.z = (!mk || ov.z > 0.f) ? v.z : 0.f; v.w = (!mk || ov.w > 0.f) ? v.w : 0.f;
+                }
+                const bool st = ok && (mk || !(acc_old && zero));
+                float4* o = st ? reinterpret_cast<float4*>(&a.y[(size_t)pix * a.ldy + col]) : dump;
+                *o = v;
+                if constexpr (DGRAD) {
+                    // same expressions as k_bn_bwd_reduce (bn.hip): the ReLU pattern from the forward's own formula
+                    const float4 yv = yvv[j];
+                    float4 g = v;
+                    g.x = (!relu2 || (yv.x - f_mu.x) * f_sc.x + f_sh.x > 0.f) ? g.x : 0.f;
+                    g.y = (!relu2 || (yv.y - f_mu.y) * f_sc.y + f_sh.y > 0.f) ? g.y : 0.f;
+                    g.z = (!relu2 || (yv.z - f_mu.z) * f_sc.z + f_sh.z > 0.f) ? g.z : 0.f;
+                    g.w = (!relu2 || (yv.w - f_mu.w) * f_sc.w + f_sh.w > 0.f) ? g.w : 0.f;
+                    g.x = ok ? g.x : 0.f; g.y = ok ? g.y : 0.f; g.z = ok ? g.z : 0.f; g.w = ok ? g.w : 0.f;
+                    fs[0] += g.x; fs[1] += g.y; fs[2] += g.z; fs[3] += g.w;
+                    fq[0] += g.x * ((yv.x - f_mu.x) * f_is.x); fq[1] += g.y * ((yv.y - f_mu.y) * f_is.y);
+                    fq[2] += g.z * ((yv.z - f_mu.z) * f_is.z); fq[3] += g.w * ((yv.w - f_mu.w) * f_is.w);
                 }
             }
         }

@@ -28,6 +28,7 @@
 namespace iswm {
 
 static __device__ __attribute__((aligned(128))) unsigned short g_zero_row_pl2t[64];
+static __device__ float4 g_dump_pl2t[64];        // where the epilogue's out-of-range lanes store (never read)
 
 typedef __attribute__((address_space(3))) void* lds_vptr2t;
 typedef float f32x4t __attribute__((ext_vector_type(4)));
@@ -270,18 +271,25 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2t(const AsppArgs a) {
                 pix[rb] = ((code >> 20) * GH + ((code >> 10) & 1023)) * GW + (code & 1023);
             }
         }
-        if (DGRAD && a.accumulate) {
+        // branch-free (see k_conv_pl2's epilogue): out-of-range lanes read a zero line / store into a dump slot by address select
+        const float4* const zero4 = reinterpret_cast<const float4*>(g_zero_row_pl2t);
+        float4* const dump = g_dump_pl2t + lane;
+        if constexpr (DGRAD) {
+            const bool acc_old = a.accumulate != 0;
 #pragma unroll
-            for (int rb = 0; rb < RBW; ++rb)
-                if (cok && pix[rb] >= 0) oldv[rb] = *reinterpret_cast<const float4*>(&yb[(size_t)pix[rb] * a.ldy + col]);
+            for (int rb = 0; rb < RBW; ++rb) {
+                const bool ok = cok && pix[rb] >= 0 && acc_old;
+                const float4* po = ok ? reinterpret_cast<const float4*>(&yb[(size_t)(ok ? pix[rb] : 0) * a.ldy + col]) : zero4;
+                oldv[rb] = *po;
+            }
         }
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) {
-            if (cok && pix[rb] >= 0) {
-                float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
-                v.x += oldv[rb].x; v.y += oldv[rb].y; v.z += oldv[rb].z; v.w += oldv[rb].w;
-                *reinterpret_cast<float4*>(&yb[(size_t)pix[rb] * a.ldy + col]) = v;
-            }
+            const bool ok = cok && pix[rb] >= 0;
+            float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+            v.x += oldv[rb].x; v.y += oldv[rb].y; v.z += oldv[rb].z; v.w += oldv[rb].w;
+            float4* o = ok ? reinterpret_cast<float4*>(&yb[(size_t)(ok ? pix[rb] : 0) * a.ldy + col]) : dump;
+            *o = v;
         }
         if (!DGRAD && a.stats[P.jobs[job].branch] != nullptr) {
             float* stp = a.stats[P.jobs[job].branch];

@@ -20,6 +20,7 @@
 namespace iswm {
 
 static __device__ __attribute__((aligned(128))) unsigned short g_zero_row_pl2w[64];   // 128 B of zeros
+static __device__ float4 g_dump_pl2w[64];        // where the epilogue's out-of-range lanes store (never read)
 
 typedef __attribute__((address_space(3))) void* lds_vptr2w;
 typedef float f32x4w __attribute__((ext_vector_type(4)));
@@ -268,62 +269,81 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
                     f_sh = *reinterpret_cast<const float4*>(a.bnf.mshift + col);
                 }
             }
-            // everything the epilogue reads is fetched before its first store (two halves of the row blocks)
-            constexpr int EH = (RBW + 1) / 2;
+            if constexpr (!DGRAD) {
+                // FORWARD: BRANCH-FREE (see k_conv_pl2's epilogue: a predicate around each store made hipcc wait vmcnt(0) before
+                // every one of them, i.e. every store waited for the previous store's acknowledgement): out-of-range lanes
+                // store into a per-lane dump slot, selected by address
+                float4* const dump = g_dump_pl2w + lane;
 #pragma unroll
-            for (int h0 = 0; h0 < RBW; h0 += EH) {
-                float4 oldv[EH], yvv[EH];
-                uint2 mkv[EH];
-                if constexpr (DGRAD) {
-#pragma unroll
-                    for (int j = 0; j < EH; ++j) {
-                        const int rb = h0 + j;
-                        const int row = m0 + rb * 16 + lp;
-                        oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        yvv[j] = oldv[j];
-                        mkv[j] = make_uint2(0u, 0u);
-                        if (rb < RBW && cok && row < a.M) {
-                            if (a.accumulate) oldv[j] = *reinterpret_cast<const float4*>(&a.y[(size_t)row * a.ldy + col]);
-                            if (bnf) yvv[j] = *reinterpret_cast<const float4*>(a.bnf.y + (size_t)row * a.bnf.ldy + col);
-                            if (mk) mkv[j] = *reinterpret_cast<const uint2*>(a.bnf.mask + (size_t)row * a.bnf.ldm + col);
+                for (int rb = 0; rb < RBW; ++rb) {
+                    const int row = m0 + rb * 16 + lp;
+                    const bool ok = cok && row < a.M;
+                    float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                    : make_float4(acc[cb][rb][0], acc[cb][rb][1], acc[cb][rb][2], acc[cb][rb][3]);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    float4* o = ok ? reinterpret_cast<float4*>(&a.y[(size_t)(ok ? row : 0) * a.ldy + col]) : dump;
+                    *o = v;
+                }
+            } else {
+                // DATA GRADIENT: the predicated form (the branch-free one spills at RBW 9 / 10: 72-80 accumulators + 48 weight
+                // registers leave no room for the selected addresses)
+                // everything the epilogue reads is fetched before its first store (two halves of the row blocks)
+                constexpr int EH = (RBW + 1) / 2;
+    #pragma unroll
+                for (int h0 = 0; h0 < RBW; h0 += EH) {
+                    float4 oldv[EH], yvv[EH];
+                    uint2 mkv[EH];
+                    if constexpr (DGRAD) {
+    #pragma unroll
+                        for (int j = 0; j < EH; ++j) {
+                            const int rb = h0 + j;
+                            const int row = m0 + rb * 16 + lp;
+                            oldv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            yvv[j] = oldv[j];
+                            mkv[j] = make_uint2(0u, 0u);
+                            if (rb < RBW && cok && row < a.M) {
+                                if (a.accumulate) oldv[j] = *reinterpret_cast<const float4*>(&a.y[(size_t)row * a.ldy + col]);
+                                if (bnf) yvv[j] = *reinterpret_cast<const float4*>(a.bnf.y + (size_t)row * a.bnf.ldy + col);
+                                if (mk) mkv[j] = *reinterpret_cast<const uint2*>(a.bnf.mask + (size_t)row * a.bnf.ldm + col);
+                            }
                         }
                     }
-                }
-#pragma unroll
-                for (int j = 0; j < EH; ++j) {
-                    const int rb = h0 + j;
-                    if (rb >= RBW) continue;
-                    const int row = m0 + rb * 16 + lp;
-                    if (cok && row < a.M) {
-                        float4* o = reinterpret_cast<float4*>(&a.y[(size_t)row * a.ldy + col]);
-                        float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                        : make_float4(acc[cb][rb][0], acc[cb][rb][1], acc[cb][rb][2], acc[cb][rb][3]);
-                        if (DGRAD && a.accumulate) {
-                            const float4 old = oldv[j];
-                            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-                        } else {
-                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        }
-                        if (mk) {
-                            // residual producer: pattern from the hi plane of its saved output; the masked gradient is stored
-                            const float4 ov = bf16x4_to_f32(mkv[j]);
-                            v.x = ov.x > 0.f ? v.x : 0.f; v.y = ov.y > 0.f ? v.y : 0.f;
-                            v.z = ov.z > 0.f ? v.z : 0.f; v.w = ov.w > 0.f ? v.w : 0.f;
-                            *o = v;
-                        } else if (!(DGRAD && a.accumulate && zero)) *o = v;
-                        if (bnf) {
-                            // same expressions as k_bn_bwd_reduce (bn.hip) and k_conv_pl2
-                            const float4 yv = yvv[j];
-                            float4 g = v;
-                            if (a.bnf.relu == 2) {
-                                g.x = (yv.x - f_mu.x) * f_sc.x + f_sh.x > 0.f ? g.x : 0.f;
-                                g.y = (yv.y - f_mu.y) * f_sc.y + f_sh.y > 0.f ? g.y : 0.f;
-                                g.z = (yv.z - f_mu.z) * f_sc.z + f_sh.z > 0.f ? g.z : 0.f;
-                                g.w = (yv.w - f_mu.w) * f_sc.w + f_sh.w > 0.f ? g.w : 0.f;
+    #pragma unroll
+                    for (int j = 0; j < EH; ++j) {
+                        const int rb = h0 + j;
+                        if (rb >= RBW) continue;
+                        const int row = m0 + rb * 16 + lp;
+                        if (cok && row < a.M) {
+                            float4* o = reinterpret_cast<float4*>(&a.y[(size_t)row * a.ldy + col]);
+                            float4 v = zero ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                            : make_float4(acc[cb][rb][0], acc[cb][rb][1], acc[cb][rb][2], acc[cb][rb][3]);
+                            if (DGRAD && a.accumulate) {
+                                const float4 old = oldv[j];
+                                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                            } else {
+                                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                             }
-                            fs[0] += g.x; fs[1] += g.y; fs[2] += g.z; fs[3] += g.w;
-                            fq[0] += g.x * ((yv.x - f_mu.x) * f_is.x); fq[1] += g.y * ((yv.y - f_mu.y) * f_is.y);
-                            fq[2] += g.z * ((yv.z - f_mu.z) * f_is.z); fq[3] += g.w * ((yv.w - f_mu.w) * f_is.w);
+                            if (mk) {
+                                // residual producer: pattern from the hi plane of its saved output; the masked gradient is stored
+                                const float4 ov = bf16x4_to_f32(mkv[j]);
+                                v.x = ov.x > 0.f ? v.x : 0.f; v.y = ov.y > 0.f ? v.y : 0.f;
+                                v.z = ov.z > 0.f ? v.z : 0.f; v.w = ov.w > 0.f ? v.w : 0.f;
+                                *o = v;
+                            } else if (!(DGRAD && a.accumulate && zero)) *o = v;
+                            if (bnf) {
+                                // same expressions as k_bn_bwd_reduce (bn.hip) and k_conv_pl2
+                                const float4 yv = yvv[j];
+                                float4 g = v;
+                                if (a.bnf.relu == 2) {
+                                    g.x = (yv.x - f_mu.x) * f_sc.x + f_sh.x > 0.f ? g.x : 0.f;
+                                    g.y = (yv.y - f_mu.y) * f_sc.y + f_sh.y > 0.f ? g.y : 0.f;
+                                    g.z = (yv.z - f_mu.z) * f_sc.z + f_sh.z > 0.f ? g.z : 0.f;
+                                    g.w = (yv.w - f_mu.w) * f_sc.w + f_sh.w > 0.f ? g.w : 0.f;
+                                }
+                                fs[0] += g.x; fs[1] += g.y; fs[2] += g.z; fs[3] += g.w;
+                                fq[0] += g.x * ((yv.x - f_mu.x) * f_is.x); fq[1] += g.y * ((yv.y - f_mu.y) * f_is.y);
+                                fq[2] += g.z * ((yv.z - f_mu.z) * f_is.z); fq[3] += g.w * ((yv.w - f_mu.w) * f_is.w);
+                            }
                         }
                     }
                 }
