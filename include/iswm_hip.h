@@ -143,10 +143,6 @@ int iswm_gap_fwd_pl(const void* x, int64_t x_ps, int N, int HW, int C, int ldx, 
 int iswm_bcast_fwd_pl(const float* v, int N, int HW, int C, void* y, int ldy, int64_t y_ps, iswm_stream_t stream);
 int iswm_bilinear_fwd_pl(const float* x, int N, int Hi, int Wi, int C, int ldx, void* y, int64_t y_ps, int Ho, int Wo,
                          int ldy, iswm_stream_t stream);
-int iswm_conv2d_fwd_planes(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
-                           const float* bias, float* y, float* stat_partials, iswm_stream_t stream);
-int iswm_conv2d_dgrad_planes(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
-                             float* dx, int accumulate, iswm_stream_t stream);
 /* diagnostics: per-stage shader-clock stamps of workgroup 0 of the planes conv kernels into a device buffer of >= 512 uint64
  * (NULL = off, the default; tools/pl2_timeline.py) */
 int iswm_set_debug_buffer(void* buf);

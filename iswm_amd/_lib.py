@@ -50,8 +50,6 @@ _SIGS = {
     "iswm_gap_fwd_pl": (c_int, [P, c_int64, c_int, c_int, c_int, c_int, P, P]),
     "iswm_bcast_fwd_pl": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int64, P]),
     "iswm_bilinear_fwd_pl": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, c_int, c_int, P]),
-    "iswm_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, P, P, P]),
-    "iswm_conv2d_dgrad_planes": (c_int, [POINTER(ConvDesc), P, c_int64, P, P, c_int, P]),
     "iswm_set_debug_buffer": (c_int, [P]),
     "iswm_conv2d_pl2_weight_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "iswm_conv2d_pl2_pack_weights": (c_int, [POINTER(ConvDesc), c_int, P, P, P]),

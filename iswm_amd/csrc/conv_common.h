@@ -39,7 +39,7 @@ struct ConvArgs {
     int nsplit;  // wgrad: K splits
     int psplit;  // wgrad: pixels per split (multiple of 32)
     int accumulate;  // dgrad: dx += result instead of dx = result
-    long long xps;   // plane kernels (conv_mfma_pl.hip): byte stride between the bf16 planes of the gathered operand
+    long long xps;   // plane kernels (conv_mfma_pl2*.hip): byte stride between the bf16 planes of the gathered operand
     int porder;                // strided dgrad of the planes kernels: the four parity quarters of the M tiles, heaviest first (2 bits each)
     int abl;                   // timing ablations of the planes kernels (ISWM_PL2_ABL: 1 no weight loads, 2 no activation DMA, 4 no stage barrier, 8 no fragment reads): wrong results by design
     BnFuse bnf;                // planes data gradient: fused BatchNorm-backward statistics (part == nullptr: off)
@@ -102,8 +102,6 @@ int pack_job_blocks_x6(int Cout, int T, int Cin, bool dgrad);
 void launch_pack_weights_x6(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s);
 void launch_transpose_ohwi(const float* w, float* wt, int Cout, int T, int Cin, hipStream_t s);
 
-// pre-split ("planes") activations, LDS-DMA staged (conv_mfma_pl.hip)
-bool launch_conv_pl(ConvArgs a, hipStream_t s, bool dgrad, int bm, int planes);
 void launch_join_planes(const unsigned short* in, int ldp, int64_t ps, int64_t M, int C, float* x, int ldx, hipStream_t s);
 void launch_split_planes(const float* x, int64_t M, int C, int ldx, unsigned short* out, int ldp, int64_t pstride_elems,
                          int planes, hipStream_t s);

@@ -1123,42 +1123,6 @@ extern "C" int iswm_join_planes(const void* planes, int ldp, int64_t plane_strid
     return check_launch("join_planes");
 }
 
-extern "C" int iswm_conv2d_fwd_planes(const iswm_conv_desc* d, const void* xp, int64_t plane_stride, const void* wpk,
-                                      const float* bias, float* y, float* stat_partials, iswm_stream_t stream) {
-    if (int e = validate(d)) return e;
-    ISWM_REQUIRE(xp && wpk && y, "conv_fwd_planes: null pointer");
-    ISWM_REQUIRE(aligned16(xp) && aligned16(wpk) && aligned16(y), "conv_fwd_planes: pointers must be 16-byte aligned");
-    ISWM_REQUIRE(d->Cin % 32 == 0 && d->ldx % 8 == 0 && plane_stride % 8 == 0, "conv_fwd_planes: Cin %% 32, ldx %% 8, plane stride %% 8");
-    ConvArgs a = base_args(d);
-    a.x = reinterpret_cast<const float*>(xp); a.w = reinterpret_cast<const float*>(wpk); a.bias = bias; a.y = y;
-    a.stats = stat_partials;
-    a.xps = plane_stride * 2;
-    a.M = d->N * d->Ho * d->Wo;
-    a.Ktot = d->KH * d->KW * d->Cin;
-    int bm, bn;
-    conv_pick_tile_x6(a.M, d->Cout, a.Ktot, false, d->KH * d->KW == 1, &bm, &bn);
-    launch_conv_pl(a, (hipStream_t)stream, false, bm, math_planes());
-    return check_launch("conv_fwd_planes");
-}
-
-extern "C" int iswm_conv2d_dgrad_planes(const iswm_conv_desc* d, const void* dyp, int64_t plane_stride, const void* wpk,
-                                        float* dx, int accumulate, iswm_stream_t stream) {
-    if (int e = validate(d)) return e;
-    ISWM_REQUIRE(dyp && wpk && dx, "conv_dgrad_planes: null pointer");
-    ISWM_REQUIRE(aligned16(dyp) && aligned16(wpk) && aligned16(dx), "conv_dgrad_planes: pointers must be 16-byte aligned");
-    ISWM_REQUIRE(d->Cout % 32 == 0 && d->ldy % 8 == 0 && plane_stride % 8 == 0, "conv_dgrad_planes: Cout %% 32, ldy %% 8, plane stride %% 8");
-    ConvArgs a = base_args(d);
-    a.x = reinterpret_cast<const float*>(dyp); a.w = reinterpret_cast<const float*>(wpk); a.y = dx; a.accumulate = accumulate;
-    a.ldx = d->ldy; a.ldy = d->ldx;
-    a.xps = plane_stride * 2;
-    a.M = d->N * d->H * d->W;
-    a.Ktot = d->KH * d->KW * d->Cout;
-    int bm, bn;
-    conv_pick_tile_x6(a.M, d->Cin, a.Ktot, true, d->KH * d->KW == 1, &bm, &bn);
-    launch_conv_pl(a, (hipStream_t)stream, true, bm, math_planes());
-    return check_launch("conv_dgrad_planes");
-}
-
 namespace iswm { extern unsigned long long* g_conv_dbg; }
 /* diagnostics: a device buffer of >= 512 uint64 that workgroup 0 of the planes conv kernels fills with per-stage shader-clock
  * stamps (tools/pl2_timeline.py); NULL (the default) switches the stamps off */
