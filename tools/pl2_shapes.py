@@ -62,20 +62,28 @@ for c in CASES:
     tf = med(lambda: ops.conv2d_fwd(x, wt, g, out=y, want_stats=True, wpk2=wpk))
     d1 = g.desc(cin, pgeom(dy)[4])
     nb = _pl2_bytes(d1, 1)
-    td = ta = float("nan")
+    td = ta = tb = float("nan")
     if nb:
         wpk1 = torch.empty((nb // 4,), device=dev)
         call("iswm_conv2d_pl2_pack_weights", ctypes.byref(d1), 1, _p(wt), _p(wpk1), _stream())
         td = med(lambda: ops.conv2d_dgrad(dy, wt, g, (n, h, w, cin), dx=dx, wpk2=wpk1))
         ta = med(lambda: ops.conv2d_dgrad(dy, wt, g, (n, h, w, cin), dx=dx, accumulate=True, wpk2=wpk1))
+        # the residual-stage form (relu code 3): accumulate + mask by the producer's saved output + its two BatchNorm sums
+        yprod = torch.randn(n, h, w, cin, device=dev)
+        coef = torch.stack([torch.ones(cin, device=dev), torch.zeros(cin, device=dev), torch.zeros(cin, device=dev), torch.ones(cin, device=dev)])
+        try:
+            tb = med(lambda: ops.conv2d_dgrad(dy, wt, g, (n, h, w, cin), dx=dx, accumulate=True, wpk2=wpk1,
+                                              bn_stats=ops.BnStats(yprod, coef, True, mask=x)))
+        except Exception as e:
+            print("   bn3 form:", str(e)[:100])
     fl = g.flops()
     dw = torch.empty(cout, k, k, cin, device=dev)
     for _ in range(2):
         ops.conv2d_wgrad(x, dy, g, dw)
     tw = med(lambda: ops.conv2d_wgrad(x, dy, g, dw))
     d7 = ops.ConvDesc(n, h, w, cin, g.ho, g.wo, cout, k, k, s, p, d, pgeom(x)[4], pgeom(dy)[4])
-    print("%-34s fwd %7.1f us %6.1f TF %-28s| dgrad %7.1f us %6.1f TF  acc %7.1f us  %s | wgrad %7.1f us %6.1f TF %s" %
-          (tag, tf, fl / tf / 1e6, _kernel_name(d0, 5), td, fl / td / 1e6, ta, _kernel_name(d1, 6) if nb else "-",
+    print("%-34s fwd %7.1f us %6.1f TF %-28s| dgrad %7.1f us %6.1f TF  acc %7.1f us  bn3 %7.1f us  %s | wgrad %7.1f us %6.1f TF %s" %
+          (tag, tf, fl / tf / 1e6, _kernel_name(d0, 5), td, fl / td / 1e6, ta, tb, _kernel_name(d1, 6) if nb else "-",
            tw, fl / tw / 1e6, _kernel_name(d7, 7)))
     tot += tf + (td if nb else 0)
     totw += tw

@@ -17,6 +17,15 @@ def step():
 step()
 torch.cuda.synchronize()
 print("warm step done", flush=True)
+# the conv launches of the second step in order (kernel name, geometry) -> PMC_SEQ file, for pmc_by_geometry.py
+from iswm_amd import ops
+seq_path = os.environ.get("PMC_SEQ")
+if seq_path:
+    ops.KPROF = ops.KernelProfile()
 step()
 torch.cuda.synchronize()
+if seq_path:
+    import json
+    json.dump([[r[0], r[4], r[3]] for r in ops.KPROF.records], open(seq_path, "w"))
+    ops.KPROF = None
 print("profiled steps done", flush=True)
