@@ -306,6 +306,17 @@ int iswm_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t M
                        iswm_stream_t stream);
 int iswm_add_inplace(float* dst, const float* src, int64_t n, iswm_stream_t stream);
 int iswm_scale_inplace(float* x, int64_t n, const float* scalar_dev, float host_mul, iswm_stream_t stream);
+/* Convolutions whose channel counts are not multiples of the kernels' granule (nn.Conv2d(3, 64, 7) at network/backbone/resnet.py:137,
+ * Conv2d(304, 256, 3) / Conv2d(256, 48, 1) / Conv2d(256, num_classes, 1) at network/_deeplab.py:36-52): zero-padded OHWI copy of an OIHW
+ * parameter with element strides[4] = (O, I, H, W); the inverse for its gradient; zero bytes [byte0, byte1) of every row of a
+ * (planes or fp32) activation buffer -- the padding channels themselves.  They replace torch.zeros / slice-copy / zero_() on the step. */
+int iswm_pad_weights(const float* w, int cout, int cin, int kh, int kw, const int64_t* strides, int cout_p, int cin_p, float* out_ohwi,
+                     iswm_stream_t stream);
+int iswm_unpad_weights(const float* dw_ohwi, int cout_p, int cin_p, int cout, int cin, int kh, int kw, float* grad,
+                       const int64_t* strides, iswm_stream_t stream);
+/* the flat gradient arena of the fused optimizers before a backward pass (optimizer.zero_grad(), train.py:607) */
+int iswm_fill_zero(void* p, size_t bytes, iswm_stream_t stream);
+int iswm_zero_cols(void* y, int64_t M, int64_t ld_bytes, int byte0, int byte1, int64_t plane_bytes, int nplanes, iswm_stream_t stream);
 /* nn.Dropout(p), network/_deeplab.py:165: counter-based Philox mask */
 int iswm_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
                      uint64_t offset, iswm_stream_t stream);

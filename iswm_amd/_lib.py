@@ -101,6 +101,10 @@ _SIGS = {
     "iswm_copy_channels": (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
     "iswm_add_inplace": (c_int, [P, P, c_int64, P]),
     "iswm_scale_inplace": (c_int, [P, c_int64, P, c_float, P]),
+    "iswm_pad_weights": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P]),
+    "iswm_unpad_weights": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "iswm_fill_zero": (c_int, [P, c_size_t, P]),
+    "iswm_zero_cols": (c_int, [P, c_int64, c_int64, c_int, c_int, c_int64, c_int, P]),
     "iswm_dropout_fwd": (c_int, [P, P, P, c_int64, c_float, c_uint64, c_uint64, P]),
     "iswm_dropout_bwd": (c_int, [P, P, P, c_int64, c_float, P]),
     "iswm_loss_blocks": (c_int, [c_int64]),

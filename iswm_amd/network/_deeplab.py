@@ -248,7 +248,7 @@ class DeepLabHeadV3Plus(_hip.HipModule):
         else:
             cat = ops.new_act(n, hl, wl, c_buf, low.device)
         if c_buf > c_cat:
-            cat[..., c_cat:].zero_()
+            ops.zero_channels(cat, c_cat)
         self.project.fwd(low, save, out=cat[..., :c_low])
         a = self.aspp.fwd(hi, save)
         ops.bilinear_fwd(a, hl, wl, out=cat[..., c_low:c_cat])

@@ -165,10 +165,7 @@ class Conv2d(HipModule, nn.Conv2d):
         v = w.permute(0, 2, 3, 1)
         if not self.needs_pack():
             return v if v.is_contiguous() else v.contiguous()
-        k = self.kernel_size[0]
-        wp = torch.zeros((self.cout_p, k, k, self.cin_p), dtype=w.dtype, device=w.device)
-        wp[:self.out_channels, :, :, :self.in_channels] = v
-        return wp
+        return ops.pad_weights(w, self.cout_p, self.cin_p)
 
     def packed2(self, kind):
         """this weight pre-packed for the planes kernels (csrc/conv_mfma_pl2.hip) by the WeightPacker, or None"""
@@ -193,9 +190,7 @@ class Conv2d(HipModule, nn.Conv2d):
             return None
         if self.cout_p == self.out_channels:
             return self.bias
-        b = torch.zeros((self.cout_p,), dtype=self.bias.dtype, device=self.bias.device)
-        b[:self.out_channels] = self.bias
-        return b
+        return ops.pad_weights(self.bias.view(-1, 1, 1, 1), self.cout_p, 1).view(-1)
 
     def geometry(self, x):
         if x.shape[3] != self.cin_p:
@@ -215,8 +210,7 @@ class Conv2d(HipModule, nn.Conv2d):
         if not self.needs_pack() and v.is_contiguous():
             ops.conv2d_wgrad(x, dy, g, v)
         else:
-            dw = ops.conv2d_wgrad(x, dy, g)
-            buf.copy_(dw[:self.out_channels, :, :, :self.in_channels].permute(0, 3, 1, 2))
+            ops.unpad_weights(ops.conv2d_wgrad(x, dy, g), buf)
         sink.done(p)
 
     # -- standalone conv (+bias), e.g. the final 1x1 classifier ---------------------------
@@ -230,7 +224,7 @@ class Conv2d(HipModule, nn.Conv2d):
         x, g = self._saved
         self._saved = None
         if self.bias is not None and self.bias.requires_grad:
-            sink.target(self.bias).copy_(ops.colsum(dy)[:self.out_channels])
+            ops.unpad_weights(ops.colsum(dy).view(-1, 1, 1, 1), sink.target(self.bias).view(-1, 1, 1, 1))
             sink.done(self.bias)
         self.write_wgrad(x, dy, g, sink)
         if not need_dx:
@@ -271,7 +265,7 @@ class DepthwiseConv2d(HipModule, nn.Conv2d):
         x, g = self._saved
         self._saved = None
         if self.bias is not None and self.bias.requires_grad:
-            sink.target(self.bias).copy_(ops.colsum(dy)[:self.out_channels])
+            ops.unpad_weights(ops.colsum(dy).view(-1, 1, 1, 1), sink.target(self.bias).view(-1, 1, 1, 1))
             sink.done(self.bias)
         if self.weight.requires_grad:
             buf = sink.target(self.weight)
@@ -447,7 +441,7 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False, 
         return conv.bwd(dy, sink, need_dx, dx, accumulate), dres
     conv.write_wgrad(x, dy, g, sink)
     if conv.bias is not None and conv.bias.requires_grad:
-        sink.target(conv.bias).copy_(ops.colsum(dy)[:conv.out_channels])
+        ops.unpad_weights(ops.colsum(dy).view(-1, 1, 1, 1), sink.target(conv.bias).view(-1, 1, 1, 1))
         sink.done(conv.bias)
     if sep is not None:
         dmid = ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), wpk=conv.packed(1), wpk2=conv.packed2(1))

@@ -143,6 +143,36 @@ def xgeom(x):
     return (x,) + geom(x) + (0,)
 
 
+def pad_weights(w, cout_p, cin_p):
+    """zero-padded OHWI [cout_p, KH, KW, cin_p] copy of an OIHW parameter (any strides)"""
+    cout, cin, kh, kw = w.shape
+    out = torch.empty((cout_p, kh, kw, cin_p), dtype=torch.float32, device=w.device)
+    st = (ctypes.c_int64 * 4)(*w.stride())
+    call("iswm_pad_weights", _p(w), cout, cin, kh, kw, st, cout_p, cin_p, _p(out), _stream())
+    return out
+
+
+def unpad_weights(dw_ohwi, grad):
+    """grad (OIHW view, any strides) <- the leading [cout, :, :, cin] block of a padded OHWI gradient"""
+    cout_p, kh, kw, cin_p = dw_ohwi.shape
+    cout, cin = grad.shape[0], grad.shape[1]
+    assert dw_ohwi.is_contiguous() and tuple(grad.shape[2:]) == (kh, kw)
+    st = (ctypes.c_int64 * 4)(*grad.stride())
+    call("iswm_unpad_weights", _p(dw_ohwi), cout_p, cin_p, cout, cin, kh, kw, _p(grad), st, _stream())
+    return grad
+
+
+def zero_channels(t, c0):
+    """zero channels [c0, C) of an NHWC activation (fp32 tensor or Planes): the padding channels of a concatenation buffer"""
+    if isinstance(t, Planes):
+        n, h, w, c, ld, ps = pgeom(t)
+        call("iswm_zero_cols", _p(t.t), n * h * w, ld * 2, c0 * 2, c * 2, (ps if ps > 0 else 0) * 2, t.t.shape[0], _stream())
+    else:
+        n, h, w, c, ld = geom(t)
+        call("iswm_zero_cols", _p(t), n * h * w, ld * 4, c0 * 4, c * 4, 0, 1, _stream())
+    return t
+
+
 def split_planes(x, out=None):
     """fp32 NHWC -> Planes (one extra pass; producers normally write planes themselves)"""
     n, h, w, c, ld = geom(x)
@@ -469,7 +499,9 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
     if isinstance(x, Planes) and planes_on() and _WGRAD_PLANES and _wgrad_planes_ok(x, dy, g, c8):
         if not isinstance(dy, Planes) or c8 != g.cout:
             dyf = as_f32(dy)
-            dy = new_planes(g.n, g.ho, g.wo, c8, x.device, zero=c8 != g.cout)
+            dy = new_planes(g.n, g.ho, g.wo, c8, x.device)
+            if c8 != g.cout:
+                zero_channels(dy, g.cout)
             split_planes(dyf, out=dy[..., :g.cout] if c8 != g.cout else dy)
         _, _, _, _, ldx, psx = pgeom(x)
         _, _, _, _, ldy, psy = pgeom(dy)
@@ -480,7 +512,7 @@ def conv2d_wgrad(x, dy, g, dw_ohwi=None):
         with _timed(d, 7, g, "+reduce"):
             call("iswm_conv2d_wgrad_planes", ctypes.byref(d), _p(x.t), psx, _p(dy.t), psy, _p(tgt), _p(ws), need, _stream())
         if tgt is not dw_ohwi:
-            dw_ohwi.copy_(tgt[:g.cout])
+            unpad_weights(tgt, dw_ohwi.permute(0, 3, 1, 2))
         return dw_ohwi
     x, dy = as_f32(x), as_f32(dy)
     ldx, ldy = geom(x)[4], geom(dy)[4]

@@ -55,7 +55,10 @@ class ParamArena:
         return torch.as_strided(flat, p.shape, p.stride(), o)
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            ops.call("iswm_fill_zero", ops._p(self.grad), self.grad.numel() * 4, ops._stream())
+        else:
+            self.grad.zero_()
         for p in self.params:
             p.grad = None
 

@@ -502,3 +502,37 @@ def test_loss_all_pixels_ignored_matches_torch():
     f = FocalLoss(alpha=0.25, gamma=2.0, ignore_index=255)(x, lab.to(dev()))
     f.backward()
     assert float(f.detach()) == 0.0 and float(x.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_weight_padding_helpers_are_bit_exact(channels_last):
+    """iswm_pad_weights / iswm_unpad_weights / iswm_zero_cols: the zero-padded OHWI copy of an OIHW parameter (either
+    memory format), its inverse for the gradient, and the zero channels of a concatenation buffer -- against slicing."""
+    from iswm_amd import ops
+    d = dev()
+    for cout, cin, k, cout_p, cin_p in ((64, 3, 7, 64, 4), (2, 256, 1, 4, 256), (256, 304, 3, 256, 320), (48, 256, 1, 48, 256)):
+        w = rnd(cout, cin, k, k, seed=cout + cin).to(d)
+        if channels_last:
+            w = w.contiguous(memory_format=torch.channels_last)
+        wp = ops.pad_weights(w, cout_p, cin_p)
+        ref = torch.zeros(cout_p, k, k, cin_p, device=d)
+        ref[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+        assert torch.equal(wp, ref)
+        g = torch.full_like(w, 7.0)
+        dw = rnd(cout_p, k, k, cin_p, seed=5).to(d)
+        ops.unpad_weights(dw, g)
+        assert torch.equal(g, dw[:cout, :, :, :cin].permute(0, 3, 1, 2))
+        assert g.stride() == w.stride()
+    b = rnd(2, seed=9).to(d)
+    bp = ops.pad_weights(b.view(-1, 1, 1, 1), 4, 1).view(-1)
+    assert torch.equal(bp, torch.cat([b, torch.zeros(2, device=d)]))
+    x = rnd(2, 5, 7, 320, seed=3).to(d)
+    y = x.clone()
+    ops.zero_channels(y, 304)
+    assert torch.equal(y[..., :304], x[..., :304]) and not y[..., 304:].any()
+    p = ops.split_planes(x)
+    keep = p.t.clone()
+    ops.zero_channels(p, 304)
+    assert torch.equal(p.t[..., :304], keep[..., :304]) and not p.t[..., 304:].any()
+    v = ops.zero_channels(ops.split_planes(x[..., :8].contiguous()), 4)          # the few-channel gradient: 4 -> 8
+    assert not v.t[..., 4:].any() and torch.equal(v.t[..., :4], keep[..., :4])
