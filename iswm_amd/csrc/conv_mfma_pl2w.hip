@@ -125,8 +125,24 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
         if (a.pad < 4) return true;                       // the vote only where padding is deep (ASPP rates)
         return __syncthreads_or(any) != 0;
     };
-    int tap = -1, cc = nCC - 1;
+    // K order of a tile's stages: tap-major (all channel chunks of a tap, then the next tap: one pointer set-up per tap) or, korder = 1,
+    // CHUNK-major (all taps of a 64-channel chunk, then the next chunk): the taps of a KxK filter read the same input rows shifted by
+    // a pixel or a row, so with the taps innermost a workgroup re-reads a window of (tile + halo) x 64 channels while it is still in
+    // L2 instead of (tile + halo) x all channels -- on the 129x129 maps the first form missed L2 on every tap (6x the operand bytes
+    // crossed the fabric).  Only where no tap can be skipped (pad < 4: the host sets it).
+    const bool kmaj = a.korder != 0;
+    int tap = -1, cc = kmaj ? 0 : nCC - 1;
     auto next_in_tile = [&]() __attribute__((always_inline)) -> bool {
+        if (kmaj) {
+            if (++tap >= taps) {
+                tap = 0;
+                if (++cc >= nCC) return false;
+            }
+            setup_tap(tap);
+#pragma unroll
+            for (int i = 0; i < NRG; ++i) aptr[i] += cc * astep[i];
+            return true;
+        }
         if (++cc < nCC) return true;
         cc = 0;
         do {
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
         if (i_tile >= ntiles) return false;
         load_tile(i_tile);
         tap = -1;
-        cc = nCC - 1;
+        cc = kmaj ? 0 : nCC - 1;
         return true;
     };
     auto next_tile_stage = [&]() __attribute__((always_inline)) -> bool {
@@ -488,6 +504,7 @@ bool launch_conv_pl2w(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw
     a.MT = (a.M + rbw * 16 - 1) / (rbw * 16);
     a.NT = (nc + 255) / 256;
     a.psplit = 1;
+    a.korder = pl2_korder(a, dgrad, true);
     const int tiles = a.MT * a.NT;
     dim3 grid(tiles < ncu ? tiles : ncu), blk(512);
 #define PL2W_LAUNCH(R)                                                                     \
