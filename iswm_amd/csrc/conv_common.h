@@ -94,6 +94,11 @@ __device__ __forceinline__ void x6_row_pixel(int m, int N, int RH, int RW, bool 
     rw = 2 * (rem - i * Wc) + pw;
 }
 
+// the 7x7 stride-2 stem as a GEMM of its own (conv_stem.hip), conv math bf16x6
+bool stem_geometry(const ConvArgs& a);
+int stem_tile_rows();
+bool launch_stem_fwd(ConvArgs a, hipStream_t s);
+
 // bf16x6 path (conv_mfma_x6.hip): fp32-accurate products from six bf16 MFMAs
 bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn);
 bool launch_conv_dgrad_x6(ConvArgs a, hipStream_t s, int bm, int bn);

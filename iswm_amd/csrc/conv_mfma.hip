@@ -875,6 +875,8 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
             if (conv_math() == 1) conv_pick_tile_x6(M, d->Cout, d->KH * d->KW * d->Cin, false, d->KH * d->KW == 1, &bm, &bn);
             else conv_pick_tile(M, d->Cout, &bm, &bn);
             snprintf(buf, buflen, conv_math() == 1 ? "k_conv_x6<%d, %d, false, false, 3>" : "k_conv_fwd_u<%d, %d>", bm, bn);
+        } else if (conv_math() == 1 && stem_geometry(base_args(d))) {
+            snprintf(buf, buflen, "k_stem_fwd<%d>", stem_tile_rows() / 16);
         } else {
             snprintf(buf, buflen, "k_conv_fwd<%d>", use_narrow_tile((M + 127) / 128, d->Cout) ? 64 : 128);
         }
@@ -900,6 +902,7 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
 
 extern "C" int iswm_conv2d_stat_tile_rows(const iswm_conv_desc* d) {
     if (!d) return 0;
+    if (conv_math() == 1 && stem_geometry(base_args(d))) return stem_tile_rows();
     if (conv_math() == 1 && d->Cin % 32 == 0) {
         int bm, bn;
         conv_pick_tile_x6((int64_t)d->N * d->Ho * d->Wo, d->Cout, d->KH * d->KW * d->Cin, false, d->KH * d->KW == 1, &bm, &bn);
@@ -925,6 +928,7 @@ extern "C" int iswm_conv2d_fwd(const iswm_conv_desc* d, const float* x, const fl
     a.Ktot = d->KH * d->KW * d->Cin;
     a.MT = (a.M + 127) / 128;
     hipStream_t s = (hipStream_t)stream;
+    if (conv_math() == 1 && launch_stem_fwd(a, s)) return check_launch("stem_fwd");
     if (conv_math() == 1 && d->Cin % 32 == 0) {
         int bm, bn;
         conv_pick_tile_x6(a.M, d->Cout, a.Ktot, false, d->KH * d->KW == 1, &bm, &bn);

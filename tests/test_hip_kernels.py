@@ -52,7 +52,8 @@ CONV_CASES = [
     (64, 256, 3, 1, 36, 36, 41, 41, 1),
     (304, 256, 3, 1, 1, 1, 21, 21, 1),      # decoder: Cin not a multiple of 32
     (256, 48, 1, 1, 0, 1, 21, 21, 2),       # low-level projection: Cout = 48
-    (4, 64, 7, 2, 3, 1, 65, 65, 2),         # stem on the 4-channel padded image
+    (4, 64, 7, 2, 3, 1, 65, 65, 2),         # stem on the 4-channel padded image (bf16x6: csrc/conv_stem.hip)
+    (4, 64, 7, 2, 3, 1, 30, 37, 3),         # ... even height, ragged last wave-tile
     (256, 4, 1, 1, 0, 1, 33, 33, 2),        # classifier padded to 4 classes
     (2048, 256, 1, 1, 0, 1, 1, 1, 4),       # image-pooling branch: 1x1 spatial
     (128, 512, 1, 1, 0, 1, 40, 40, 3),
@@ -536,3 +537,24 @@ def test_weight_padding_helpers_are_bit_exact(channels_last):
     assert torch.equal(p.t[..., :304], keep[..., :304]) and not p.t[..., 304:].any()
     v = ops.zero_channels(ops.split_planes(x[..., :8].contiguous()), 4)          # the few-channel gradient: 4 -> 8
     assert not v.t[..., 4:].any() and torch.equal(v.t[..., :4], keep[..., :4])
+
+
+def test_stem_at_production_size_vs_float64():
+    """k_stem_fwd at the production map (513 x 513, more wave-tiles than the persistent grid has waves) against float64;
+    the BatchNorm partials against the float64 batch statistics (network/backbone/resnet.py:137,145-146)."""
+    from iswm_amd import ops
+    n, h = 4, 513
+    x = rnd(n, 3, h, h, seed=11)
+    wt = rnd(64, 3, 7, 7, seed=12) * (2.0 / 147) ** 0.5
+    y_ref = F.conv2d(x.double(), wt.double(), None, 2, 3)
+    xh = nhwc(x, 4)
+    w_ohwi = torch.zeros(64, 7, 7, 4)
+    w_ohwi[..., :3] = wt.permute(0, 2, 3, 1)
+    w_ohwi = w_ohwi.to(dev())
+    g = ops.ConvGeom(xh, 64, 7, 7, 2, 3, 1)
+    y, partials, tiles = ops.conv2d_fwd(xh, w_ohwi, g, want_stats=True)
+    assert ops._kernel_name(g.desc(4, 64), 0).startswith("k_stem_fwd")
+    assert rel_err(nchw(y), y_ref) < 2e-6
+    coef = ops.bn_finalize(partials, tiles[0], n * g.ho * g.wo, tiles[1], None, None, None, None, 0.1)
+    assert rel_err(coef[2], y_ref.mean((0, 2, 3))) < 1e-5
+    assert rel_err(1.0 / coef[3].double().cpu() ** 2 - 1e-5, y_ref.var((0, 2, 3), unbiased=False)) < 1e-5
