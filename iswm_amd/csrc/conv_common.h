@@ -98,6 +98,8 @@ __device__ __forceinline__ void x6_row_pixel(int m, int N, int RH, int RW, bool 
 bool stem_geometry(const ConvArgs& a);
 int stem_tile_rows();
 bool launch_stem_fwd(ConvArgs a, hipStream_t s);
+size_t stem_wgrad_workspace(const ConvArgs& a);
+bool launch_stem_wgrad(ConvArgs a, float* dw, float* workspace, hipStream_t s);
 
 // bf16x6 path (conv_mfma_x6.hip): fp32-accurate products from six bf16 MFMAs
 bool launch_conv_fwd_x6(ConvArgs a, hipStream_t s, int bm, int bn);

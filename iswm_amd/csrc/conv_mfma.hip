@@ -891,6 +891,10 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
             snprintf(buf, buflen, "k_conv_dgrad<%d>", use_narrow_tile((M + 127) / 128, d->Cin) ? 64 : 128);
         }
     } else {
+        if (conv_math() == 1 && stem_geometry(base_args(d))) {
+            snprintf(buf, buflen, "k_stem_wgrad");
+            return 0;
+        }
         WgradPlan p = plan_wgrad(d, conv_math() >= 1);
         const bool same = d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
         const int mode = (same && d->KH == 1 && d->KW == 1 && d->pad == 0) ? 2 : (same ? 1 : 0);
@@ -1251,6 +1255,7 @@ extern "C" int iswm_conv2d_dgrad_pl2_bn(const iswm_conv_desc* d, const void* dyp
 
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
+    if (conv_math() == 1 && stem_geometry(base_args(d))) return stem_wgrad_workspace(base_args(d));
     WgradPlan p = plan_wgrad(d, conv_math() >= 1);
     if (p.nsplit <= 1) return 0;
     return (size_t)p.nsplit * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
@@ -1269,6 +1274,7 @@ extern "C" int iswm_conv2d_wgrad(const iswm_conv_desc* d, const float* x, const 
     a.x = x; a.y = const_cast<float*>(dy);
     a.M = d->N * d->Ho * d->Wo;
     a.Ktot = d->KH * d->KW * d->Cin;
+    if (conv_math() == 1 && launch_stem_wgrad(a, dw, workspace, (hipStream_t)stream)) return check_launch("stem_wgrad");
     a.MT = p.MT; a.NT = p.NT; a.nsplit = p.nsplit; a.psplit = p.psplit;
     a.stats = (p.nsplit > 1) ? workspace : dw;
     hipStream_t s = (hipStream_t)stream;

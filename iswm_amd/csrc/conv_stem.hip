@@ -182,13 +182,193 @@ __global__ __launch_bounds__(512) void k_stem_fwd(const ConvArgs a) {
     }
 }
 
+// ---- weight gradient:  dW[cout][kh][kw][c] = sum over output pixels p of dy[p][cout] * x[n, 2 oh - 3 + kh, 2 ow - 3 + kw, c]
+// GEMM rows = the 64 output channels, columns = the 7 x 32 (kernel row, 8 pixels x 4 channels) slots of the forward's K layout,
+// K = output pixels.  Both operands are K-strided in memory (channel contiguous), so they go through LDS as [pixel][channel] bf16
+// images and come out as pixel-contiguous fragments by ds_read_b64_tr_b16 -- the image layout and the fragment reader of
+// k_wgrad_pls (conv_wgrad_pl.hip): rows of 256 B = 128 channels, 16-byte group q of row r at byte (16 q) ^ (64 (r & 3)).
+//   image 0 = [dy: 64 channels | kernel row 0 | kernel row 1],  image 1 = kernel rows 2..5,  image 2 = kernel row 6
+// A workgroup walks its share of the pixels in 16-pixel stages: every thread fetches up to three float4 of the NEXT stage
+// (dy: one pixel's 4 channels; x: one input pixel, zero outside the image) before the multiply of the current one, then splits
+// them exactly into the three bf16 pieces and writes the other LDS buffer: one barrier per stage.  Waves 0..6 each own one
+// kernel row: a 64 x 32 block of dW as two 32x32x16 accumulators.  Every workgroup writes its partial dW [64][224] and a second
+// kernel sums the partials in a fixed order into the OHWI gradient (bit-reproducible, no float atomics).
+constexpr int SW_KS = 16;                      // pixels per stage
+constexpr int SW_PLANE = SW_KS * 256, SW_IMG = 3 * SW_PLANE, SW_STAGE = 3 * SW_IMG;
+
+__global__ __launch_bounds__(512) void k_stem_wgrad(const ConvArgs a, float* __restrict__ slabs, int per) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * SW_STAGE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int H = a.H, W = a.W, HoWo = a.Ho * a.Wo;
+    const int p_begin = blockIdx.x * per, p_end = min(a.M, p_begin + per);
+    const int nK = p_end > p_begin ? (p_end - p_begin + SW_KS - 1) / SW_KS : 0;
+    const float4* const x4 = reinterpret_cast<const float4*>(a.x);
+    const float4 zf = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // fetch roles.  dy: threads 0..255 -> pixel t >> 4, channels 4 (t & 15).  x: items j = t, t + 512 (< 896): pixel j / 56,
+    // kernel row (j % 56) >> 3, window pixel (j % 56) & 7
+    const int dpx = t >> 4, dc4 = t & 15;
+    int xpx[2], xkh[2], xq[2];
+    bool xon[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = t + 512 * i;
+        xon[i] = j < 16 * 56;
+        const int jj = xon[i] ? j : 0;
+        xpx[i] = jj / 56;
+        const int rem = jj - xpx[i] * 56;
+        xkh[i] = rem >> 3;
+        xq[i] = rem & 7;
+    }
+    float4 rd = zf, rx[2] = {zf, zf};
+    const float4* const zero4 = reinterpret_cast<const float4*>(g_stem_zero);
+    // this thread's x pixels as (n, oh, ow), advanced by 16 output pixels per stage (Wo > 16: at most one carry each) -- two
+    // integer divisions per item and stage cost more VALU time than the stage's matrix work
+    int xn[2], xoh[2], xow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = min(p_begin + xpx[i], a.M - 1);
+        xn[i] = p / HoWo;
+        const int rem = p - xn[i] * HoWo;
+        xoh[i] = rem / a.Wo;
+        xow[i] = rem - xoh[i] * a.Wo;
+    }
+    auto fetch = [&](int s2) __attribute__((always_inline)) {          // branch-free: a pixel that is not there reads the zero pixel;
+        const int p0 = p_begin + s2 * SW_KS;                           // called for s2 = 0, 1, 2, ... in order
+        {
+            const int p = p0 + dpx;
+            const bool ok = t < 256 && p < p_end;
+            rd = *(ok ? reinterpret_cast<const float4*>(a.y + (size_t)p * a.ldy + dc4 * 4) : zero4);          // a.y = dy
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = p0 + xpx[i];
+            const int ih = 2 * xoh[i] - 3 + xkh[i], iw = 2 * xow[i] - 3 + xq[i];
+            const bool ok = xon[i] && p < p_end && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            rx[i] = *(ok ? x4 + ((size_t)(xn[i] * H + ih) * W + iw) : zero4);
+            int ow = xow[i] + SW_KS;
+            const int c1 = ow >= a.Wo ? 1 : 0;
+            xow[i] = ow - (c1 ? a.Wo : 0);
+            const int oh = xoh[i] + c1;
+            const int c2 = oh >= a.Ho ? 1 : 0;
+            xoh[i] = c2 ? 0 : oh;
+            xn[i] += c2;
+        }
+    };
+    auto put = [&](unsigned char* img, int row, int col, const float4 v) __attribute__((always_inline)) {
+        uint2 h, m, l;
+        split3(v, h, m, l);
+        unsigned char* q = img + row * 256 + ((col * 2) ^ ((row & 3) * 64));
+        *reinterpret_cast<uint2*>(q) = h;
+        *reinterpret_cast<uint2*>(q + SW_PLANE) = m;
+        *reinterpret_cast<uint2*>(q + 2 * SW_PLANE) = l;
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* st = smem + buf * SW_STAGE;
+        if (t < 256) put(st, dpx, dc4 * 4, rd);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (xon[i]) {
+                const int kh = xkh[i];
+                const int img = kh < 2 ? 0 : (kh < 6 ? 1 : 2);
+                const int col = (kh < 2 ? 64 + 32 * kh : (kh < 6 ? 32 * (kh - 2) : 0)) + 4 * xq[i];
+                put(st + img * SW_IMG, xpx[i], col, rx[i]);
+            }
+        }
+    };
+
+    // fragment reader of k_wgrad_pls: 32 channels [col0, col0 + 32) x the stage's 16 pixels -> the 32x32x16 operand
+    const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+    const int th = tg >> 1, tc = (tg & 1) * 16 + tp * 4;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    auto tr_frag = [&](const unsigned char* plane, int col0) __attribute__((always_inline)) -> uint4 {
+        const unsigned char* q = plane + (th * 8 + tq) * 256 + (((col0 + tc) * 2) ^ (tq * 64));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q + 4 * 256));
+        uint2 a2 = __builtin_bit_cast(uint2, lo), b2 = __builtin_bit_cast(uint2, hi);
+        return make_uint4(a2.x, a2.y, b2.x, b2.y);
+    };
+    const int kh_w = wave;                                    // this wave's kernel row (wave 7 only fetches)
+    const int bimg = kh_w < 2 ? 0 : (kh_w < 6 ? 1 : 2);
+    const int bcol = kh_w < 2 ? 64 + 32 * kh_w : (kh_w < 6 ? 32 * (kh_w - 2) : 0);
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    if (nK > 0) {
+        fetch(0);
+        store(0);
+    }
+    __syncthreads();
+    for (int s2 = 0; s2 < nK; ++s2) {
+        const int buf = s2 & 1;
+        if (s2 + 1 < nK) fetch(s2 + 1);
+        if (wave < 7) {
+            const unsigned char* st = smem + buf * SW_STAGE;
+            uint4 FB[3], FA[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                FB[pl] = tr_frag(st + bimg * SW_IMG + pl * SW_PLANE, bcol);
+                FA[0][pl] = tr_frag(st + pl * SW_PLANE, 0);
+                FA[1][pl] = tr_frag(st + pl * SW_PLANE, 32);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                f32x16 c = acc[mb];
+                c = mfma_bf16(FA[mb][2], FB[0], c);     // smallest terms first
+                c = mfma_bf16(FA[mb][0], FB[2], c);
+                c = mfma_bf16(FA[mb][1], FB[1], c);
+                c = mfma_bf16(FA[mb][1], FB[0], c);
+                c = mfma_bf16(FA[mb][0], FB[1], c);
+                c = mfma_bf16(FA[mb][0], FB[0], c);
+                acc[mb] = c;
+            }
+        }
+        if (s2 + 1 < nK) store(buf ^ 1);
+        __syncthreads();
+    }
+    if (wave < 7) {
+        float* out = slabs + (size_t)blockIdx.x * 64 * 224;
+        const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[(size_t)row * 224 + kh_w * 32 + li] = acc[mb][r];
+            }
+    }
+}
+
+// dw[co][kh][kw][c] (OHWI, 4 channels) = sum over the workgroups' partials, in order
+__global__ __launch_bounds__(256) void k_stem_wgrad_reduce(const float* __restrict__ slabs, int nslab, float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 64 * 196) return;
+    const int co = idx / 196, rem = idx - co * 196;
+    const int kh = rem / 28, r2 = rem - kh * 28;
+    const float* p = slabs + (size_t)co * 224 + kh * 32 + r2;
+    float s = 0.f;
+    int b = 0;
+    for (; b + 3 < nslab; b += 4) {
+        const float v0 = p[(size_t)b * 14336], v1 = p[(size_t)(b + 1) * 14336], v2 = p[(size_t)(b + 2) * 14336],
+                    v3 = p[(size_t)(b + 3) * 14336];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < nslab; ++b) s += p[(size_t)b * 14336];
+    dw[idx] = s;
+}
+
 // the geometry this file covers (conv math bf16x6 only: the exact-fp32 mode keeps the fp32 MFMA kernels)
 bool stem_geometry(const ConvArgs& a) {
     static int on = -1;
     if (on < 0) on = (getenv("ISWM_STEM") && getenv("ISWM_STEM")[0] == '0') ? 0 : 1;       // tuning switch: 0 = the generic kernels
     return on && a.Cin == 4 && a.Cout == 64 && a.KH == 7 && a.KW == 7 && a.stride == 2 && a.pad == 3 && a.dil == 1 && a.ldx == 4 &&
            a.ldy % 4 == 0 && a.ldy >= 64 && (long long)a.N * a.H * a.W < (1ll << 29) && a.Ho == (a.H - 1) / 2 + 1 &&
-           a.Wo == (a.W - 1) / 2 + 1;
+           a.Wo == (a.W - 1) / 2 + 1 && a.Wo > 16;
 }
 
 int stem_tile_rows() { return STEM_TILE; }
@@ -205,6 +385,37 @@ bool launch_stem_fwd(ConvArgs a, hipStream_t s) {
     a.MT = (a.M + STEM_TILE - 1) / STEM_TILE;
     const int wgs = (a.MT + 7) / 8;
     hipLaunchKernelGGL((k_stem_fwd<STEM_RB>), dim3(wgs < ncu ? wgs : ncu), dim3(512), 0, s, a);
+    return true;
+}
+
+static int stem_wgrad_grid(const ConvArgs& a, int* per) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const long long M = (long long)a.N * a.Ho * a.Wo;
+    int grid = (int)((M + SW_KS - 1) / SW_KS < ncu ? (M + SW_KS - 1) / SW_KS : ncu);
+    if (grid < 1) grid = 1;
+    *per = (int)(((M + grid - 1) / grid + SW_KS - 1) / SW_KS * SW_KS);
+    return (int)((M + *per - 1) / *per);
+}
+
+size_t stem_wgrad_workspace(const ConvArgs& a) {
+    int per;
+    return (size_t)stem_wgrad_grid(a, &per) * 64 * 224 * sizeof(float);
+}
+
+// a.x: NHWC4 fp32 image, a.y: dy [M][ldy] fp32; dw: OHWI [64][7][7][4]; workspace >= stem_wgrad_workspace
+bool launch_stem_wgrad(ConvArgs a, float* dw, float* workspace, hipStream_t s) {
+    if (!stem_geometry(a)) return false;
+    int per;
+    const int grid = stem_wgrad_grid(a, &per);
+    a.M = a.N * a.Ho * a.Wo;
+    hipLaunchKernelGGL(k_stem_wgrad, dim3(grid), dim3(512), 0, s, a, workspace, per);
+    hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3((64 * 196 + 255) / 256), dim3(256), 0, s, workspace, grid, dw);
     return true;
 }
 

@@ -558,3 +558,12 @@ def test_stem_at_production_size_vs_float64():
     coef = ops.bn_finalize(partials, tiles[0], n * g.ho * g.wo, tiles[1], None, None, None, None, 0.1)
     assert rel_err(coef[2], y_ref.mean((0, 2, 3))) < 1e-5
     assert rel_err(1.0 / coef[3].double().cpu() ** 2 - 1e-5, y_ref.var((0, 2, 3), unbiased=False)) < 1e-5
+    # k_stem_wgrad: every workgroup of the grid takes a pixel range; partials summed in order -> bit-identical repeats
+    dy = rnd(n, 64, g.ho, g.wo, seed=13)
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), wt.shape, dy.double(), 2, 3)
+    dyh = nhwc(dy)
+    assert ops._kernel_name(g.desc(4, 64), 2) == "k_stem_wgrad"
+    dw = ops.conv2d_wgrad(xh, dyh, g)
+    assert rel_err(dw[..., :3].cpu().permute(0, 3, 1, 2), dw_ref) < 2e-6
+    assert not dw[..., 3].any()
+    assert torch.equal(dw, ops.conv2d_wgrad(xh, dyh, g))
