@@ -57,10 +57,11 @@ def robust_err(actual, expected, q=0.995):
     that sit within rounding of zero may get opposite signs, and with the few hundred pixels per
     channel of the golden cases ONE flipped ReLU shifts that channel's BatchNorm gradient sums, and
     with them every gradient downstream, by O(1/pixels) ~ 2e-3.  These checks therefore bound the
-    relative L2 error AND two quantiles of the element-wise error (check_grad_robust / check_robust: q90 <= 2e-3,
-    q99.5 <= 1e-2, L2 <= 5e-2 -- measured over all 278 comparisons of the suite: q90 <= 1.4e-3, q99.5 <= 5.8e-3,
-    medians ~1e-4; the L2 bound stays loose because one flipped ReLU moves ONE entry of a near-zero BatchNorm bias
-    gradient by more than that vector's own norm: L2 1.2e-2 at q99.5 5e-7 was seen): a wrong formula, layout or scale on any tensor, however small, moves the MEDIAN
+    relative L2 error AND two quantiles of the element-wise error (check_grad_robust / check_robust: q90 <= 1.2e-3,
+    q99.5 <= 8e-3, L2 <= 2e-2 -- measured over all 621 comparisons of the round-3 suite (ISWM_TEST_REPORT): q90 <= 7.5e-4,
+    q99.5 <= 5.8e-3, L2 <= 3.8e-3 with ONE exception, medians ~1e-4; the L2 bound stays above that exception: one flipped ReLU
+    moves ONE entry of a near-zero BatchNorm bias gradient by more than that vector's own norm -- L2 1.18e-2 at q99.5 5e-7.
+    The kernels are bit-reproducible, so these figures do not move from run to run or box to box): a wrong formula, layout or scale on any tensor, however small, moves the MEDIAN
     error to O(1).  The element-wise 1e-3 bound itself is enforced with identical sign patterns (same-mask tests)."""
     a = actual.detach().cpu().double().numpy() if torch.is_tensor(actual) else np.asarray(actual, dtype=np.float64)
     e = expected.detach().cpu().double().numpy() if torch.is_tensor(expected) else np.asarray(expected, dtype=np.float64)
@@ -78,7 +79,7 @@ def _report(name, a, e, qerr, l2):
             f.write("%-40s q50 %.2e q90 %.2e q99.5 %.2e L2 %.2e max %.2e\n" % (name, q50, q90, qerr, l2, rel_err(a, e)))
 
 
-Q90_TOL, Q995_TOL, L2_TOL = 2e-3, 1e-2, 5e-2
+Q90_TOL, Q995_TOL, L2_TOL = 1.2e-3, 8e-3, 2e-2
 
 
 def check_grad_robust(p_grad, fx, key, tol=Q995_TOL, l2_tol=L2_TOL):
