@@ -163,24 +163,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         if (a.pad < 4 && a.stride == 1) return true;
         return __syncthreads_or(any) != 0;
     };
-    // K order of a tile's stages: tap-major (all channel chunks of a tap, then the next tap: one pointer set-up per tap) or, korder = 1,
-    // CHUNK-major (all taps of a 64-channel chunk, then the next chunk): the taps of a KxK filter read the same input rows shifted by
-    // a pixel or a row, so with the taps innermost a workgroup re-reads a window of (tile + halo) x 64 channels while it is still in
-    // L2 instead of (tile + halo) x all channels -- on the 129x129 maps the first form missed L2 on every tap (6x the operand bytes
-    // crossed the fabric).  Only where no tap can be skipped (pad < 4: the host sets it).
-    const bool kmaj = a.korder != 0;
-    int tap = -1, cc = kmaj ? 0 : nCC - 1;
-    auto next_in_tile = [&]() __attribute__((always_inline)) -> bool {
-        if (kmaj) {
-            if (++tap >= taps) {
-                tap = 0;
-                if (++cc >= nCC) return false;
-            }
-            setup_tap(tap);
-#pragma unroll
-            for (int i = 0; i < NRG; ++i) aptr[i] += cc * astep[i];
-            return true;
-        }       // advance (tap, cc) to the next 64-channel stage of this tile with work
+    int tap = -1, cc = nCC - 1;
+    auto next_in_tile = [&]() __attribute__((always_inline)) -> bool {       // advance (tap, cc) to the next 64-channel stage of this tile with work
         if (++cc < nCC) return true;
         cc = 0;
         do {
@@ -522,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2(const ConvArgs a) {
         if (i_tile >= ntiles) return false;
         load_tile(i_tile);
         tap = -1;
-        cc = kmaj ? 0 : nCC - 1;
+        cc = nCC - 1;
         return true;
     };
     // move the issue side to the first stage of the next tile that has one; tiles without any stage (no tap reaches
@@ -681,7 +665,6 @@ bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw)
     static int abl = -1;
     if (abl < 0) abl = getenv("ISWM_PL2_ABL") ? atoi(getenv("ISWM_PL2_ABL")) : 0;
     a.abl = abl;
-    a.korder = pl2_korder(a, dgrad, false);
     const int nc = dgrad ? a.Cin : a.Cout;
     const bool narrow = nc <= 64;
     a.MT = (a.M + rbw * 16 - 1) / (rbw * 16);

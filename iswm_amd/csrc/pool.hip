@@ -90,10 +90,24 @@ __global__ __launch_bounds__(256) void k_gap_fwd(const void* __restrict__ x, int
     float4 s = make_float4(0, 0, 0, 0);
     if (rt.active) {
         const int64_t p = (int64_t)n * HW * ldx + rt.c4 * 4;
-        for (int r = rt.rl; r < HW; r += RL) {
-            float4 v = ld4x(x, p + (int64_t)r * ldx, xps);
+        // four rows in flight per thread (a thread walks HW / RL ~ 136 rows of the 33 x 33 map: one dependent load chain per row
+        // left the pass at 1.5 TB/s), summed in a fixed order
+        float4 s1 = s, s2 = s, s3 = s;
+        int r = rt.rl;
+        for (; r + 3 * RL < HW; r += 4 * RL) {
+            const float4 v0 = ld4x(x, p + (int64_t)r * ldx, xps), v1 = ld4x(x, p + (int64_t)(r + RL) * ldx, xps);
+            const float4 v2 = ld4x(x, p + (int64_t)(r + 2 * RL) * ldx, xps), v3 = ld4x(x, p + (int64_t)(r + 3 * RL) * ldx, xps);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+            s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+            s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+        }
+        for (; r < HW; r += RL) {
+            const float4 v = ld4x(x, p + (int64_t)r * ldx, xps);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+        s.x = (s.x + s1.x) + (s2.x + s3.x); s.y = (s.y + s1.y) + (s2.y + s3.y);
+        s.z = (s.z + s1.z) + (s2.z + s3.z); s.w = (s.w + s1.w) + (s2.w + s3.w);
     }
     const int t = threadIdx.x;
     st4(&red[t * 4], s);
@@ -138,10 +152,22 @@ __global__ __launch_bounds__(256) void k_bcast_bwd(const float* __restrict__ dy,
     float4 s = make_float4(0, 0, 0, 0);
     if (rt.active) {
         const float* p = dy + (size_t)n * HW * ldd + rt.c4 * 4;
-        for (int r = rt.rl; r < HW; r += RL) {
-            float4 v = ld4(p + (size_t)r * ldd);
+        float4 s1 = s, s2 = s, s3 = s;                   // four rows in flight, as k_gap_fwd
+        int r = rt.rl;
+        for (; r + 3 * RL < HW; r += 4 * RL) {
+            const float4 v0 = ld4(p + (size_t)r * ldd), v1 = ld4(p + (size_t)(r + RL) * ldd);
+            const float4 v2 = ld4(p + (size_t)(r + 2 * RL) * ldd), v3 = ld4(p + (size_t)(r + 3 * RL) * ldd);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+            s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+            s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+        }
+        for (; r < HW; r += RL) {
+            const float4 v = ld4(p + (size_t)r * ldd);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+        s.x = (s.x + s1.x) + (s2.x + s3.x); s.y = (s.y + s1.y) + (s2.y + s3.y);
+        s.z = (s.z + s1.z) + (s2.z + s3.z); s.w = (s.w + s1.w) + (s2.w + s3.w);
     }
     const int t = threadIdx.x;
     st4(&red[t * 4], s);

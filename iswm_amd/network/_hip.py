@@ -402,7 +402,7 @@ def _bn_stats_request(up):
     return ops.BnStats(up["y"], up["coef"], up["relu"])
 
 
-def cba_bwd_bn(conv, bn, ctx, dout, sink, dy_out=None):
+def cba_bwd_bn(conv, bn, ctx, dout, sink, dy_out=None, need_dx=True):
     """the BatchNorm (+ activation) backward of a stage: parameter gradients into the sink, returns (dy, dres) with dy the
     gradient of the raw conv output -- pre-split when the conv's gradient kernels take planes; dy_out: write it there (a Planes
     slice of a wider buffer: the fused ASPP data gradient reads the four branches' gradients from one tensor)"""
@@ -413,7 +413,9 @@ def cba_bwd_bn(conv, bn, ctx, dout, sink, dy_out=None):
     gw, gb = bn.weight, bn.bias
     dgamma = sink.target(gw) if gw.requires_grad else torch.empty_like(gw)
     dbeta = sink.target(gb) if gb.requires_grad else torch.empty_like(gb)
-    dyp = (not ctx.get("dw")) and ops.planes_conv_ok(conv.cin_p, conv.cout_p, 1)
+    # planes only when a planes kernel will read them: the data gradient, or the weight gradient of a pre-split input (the stem
+    # has neither: its gradient stays fp32 instead of being split here and joined again for the weight gradient)
+    dyp = (not ctx.get("dw")) and ops.planes_conv_ok(conv.cin_p, conv.cout_p, 1) and (need_dx or ops.is_planes(ctx["x"]))
     st = ctx.pop("bn_stats", None)
     if st is not None and st.partials is not None and st.masked:
         dout = ops.as_f32(dout)
@@ -434,7 +436,7 @@ def cba_bwd(conv, bn, ctx, dout, sink, need_dx=True, dx=None, accumulate=False, 
     """Returns (dx, dres): dres is the gradient of the residual input (if any).  up: see _bn_stats_request."""
     x, g = ctx["x"], ctx["g"]
     sep = ctx.get("sep")
-    dy, dres = cba_bwd_bn(conv, bn, ctx, dout, sink)
+    dy, dres = cba_bwd_bn(conv, bn, ctx, dout, sink, need_dx=need_dx or sep is not None)
     if sep is not None:
         conv = sep.body[1]
     if ctx.get("dw"):

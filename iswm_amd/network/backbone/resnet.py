@@ -58,8 +58,10 @@ class Bottleneck(_hip.HipModule):
         self._saved = (c1, c2, c3, cd) if save else None
         return out
 
-    def bwd(self, dout, sink, need_dx=True, up=None):
-        """up: the bn3 stage context of the PREVIOUS block when this block's input gradient is consumed by that stage alone
+    def bwd(self, dout, sink, need_dx=True, up=None, dx0=None):
+        """dx0: a gradient that already stands at this block's input (a tapped feature's: the decoder's low-level branch) -- the
+        block's data gradients accumulate into it instead of a separate add pass.
+        up: the bn3 stage context of the PREVIOUS block when this block's input gradient is consumed by that stage alone
         (identity blocks inside a layer): conv1's accumulating data gradient then applies that stage's ReLU pattern and takes
         its BatchNorm-backward sums (ops.BnStats.mask)"""
         c1, c2, c3, cd = self._saved
@@ -70,11 +72,13 @@ class Bottleneck(_hip.HipModule):
         if cd is not None:
             # conv1 (1x1, stride 1) writes every input pixel; the strided downsample conv then only touches the
             # pixels it reaches (its data gradient skips the other parity classes when accumulating)
-            dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink)
+            dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink, dx=dx0, accumulate=dx0 is not None)
             dx, _ = _hip.cba_bwd(self.downsample[0], self.downsample[1], cd, dres, sink, dx=dx, accumulate=True)
         else:
             # identity branch: the residual gradient IS dx; conv1's dgrad accumulates into it
             dx, _ = _hip.cba_bwd(self.conv1, self.bn1, c1, d1, sink, dx=dres, accumulate=True, up=up)
+            if dx0 is not None:
+                dx = ops.add_inplace(dx, dx0)
         return dx
 
     def out_channels_of(self, cin):
@@ -83,19 +87,21 @@ class Bottleneck(_hip.HipModule):
 
 class _Layer(_hip.HipModule, nn.Sequential):
     """nn.Sequential of Bottlenecks (reference _make_layer returns nn.Sequential)."""
+    accepts_dx0 = True          # bwd(dy, sink, dx0): IntermediateLayerGetter hands a tapped feature's gradient down
 
     def fwd(self, x, save):
         for m in self:
             x = m.fwd(x, save)
         return x
 
-    def bwd(self, dy, sink):
+    def bwd(self, dy, sink, dx0=None):
+        """dx0: see Bottleneck.bwd (handed to the first block)"""
         blocks = list(self)
         for i in range(len(blocks) - 1, -1, -1):
             up = None
             if i > 0 and blocks[i].downsample is None and blocks[i - 1]._saved is not None:
                 up = blocks[i - 1]._saved[2]            # the previous block's conv3 / bn3 / + identity / ReLU stage
-            dy = blocks[i].bwd(dy, sink, up=up)
+            dy = blocks[i].bwd(dy, sink, up=up, dx0=dx0 if i == 0 else None)
         return dy
 
     def out_channels_of(self, cin):

@@ -156,16 +156,23 @@ class IntermediateLayerGetter(nn.ModuleDict):
         inv = {v: k for k, v in self.return_layers.items()}
         tap = {inv[k]: g for k, g in dfeats.items() if g is not None}
         dy = None
-        for name in reversed(names):
+        order = list(reversed(names))
+        for k, name in enumerate(order):
             if name in tap:
-                g = tap[name]
+                g = tap.pop(name)
                 dy = g if dy is None else ops.add_inplace(dy, g)
             if name in ("relu", "bn1"):
                 continue
             if name == "conv1":
                 dy, _ = _hip.cba_bwd(self["conv1"], self["bn1"], self._saved, dy, sink, need_dx=need_dx)
             else:
-                dy = self[name].bwd(dy, sink)
+                # a tapped feature right below this layer (low_level under layer2): the layer's first block accumulates its data
+                # gradient into the tap's gradient instead of a separate 800-MB add pass
+                below = order[k + 1] if k + 1 < len(order) else None
+                if below in tap and getattr(self[name], "accepts_dx0", False) and not ops.is_planes(tap[below]):
+                    dy = self[name].bwd(dy, sink, dx0=tap.pop(below))
+                else:
+                    dy = self[name].bwd(dy, sink)
         self._saved = None
         return dy
 
