@@ -41,7 +41,6 @@ struct ConvArgs {
     int psplit;  // wgrad: pixels per split (multiple of 32)
     int accumulate;  // dgrad: dx += result instead of dx = result
     long long xps;   // plane kernels (conv_mfma_pl2*.hip): byte stride between the bf16 planes of the gathered operand
-    int korder;                // planes conv kernels: 1 = chunk-major K order (taps innermost), see k_conv_pl2
     int porder;                // strided dgrad of the planes kernels: the four parity quarters of the M tiles, heaviest first (2 bits each)
     int abl;                   // timing ablations of the planes kernels (ISWM_PL2_ABL: 1 no weight loads, 2 no activation DMA, 4 no stage barrier, 8 no fragment reads): wrong results by design
     BnFuse bnf;                // planes data gradient: fused BatchNorm-backward statistics (part == nullptr: off)
@@ -154,20 +153,6 @@ int pack_job_blocks_pl2(int Cout, int T, int Cin, bool dgrad);
 int conv_pl2_pick_rbw(int64_t M, int cols);
 void conv_pl2_plan(int64_t M, int cols, int K, bool wide_ok, int* rbw, int* wide);      // tile height and 128- / 256-column form
 bool launch_conv_pl2w(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw);  // conv_mfma_pl2w.hip
-// K order of the planes conv kernels (ConvArgs::korder): chunk-major only where no tap is ever skipped (shallow padding, stride 1),
-// the filter has taps to share rows between and more than one 64-channel chunk.  ISWM_PL2_KORDER = 0 / 1: never / wherever possible.
-// Measured (profiles/r03_korder.txt): +3...5 % for the 256-column kernel on the 129x129 maps (where the tap-major form re-fetched
-// every tap through the fabric), -3...7 % for the 128-column kernel and on the 33x33 maps (L2 holds those windows either way and
-// the per-stage pointer set-up costs more than it saves) -- hence the rule.
-inline int pl2_korder(const ConvArgs& a, bool dgrad, bool wide) {
-    static int force = -2;
-    if (force == -2) force = getenv("ISWM_PL2_KORDER") ? atoi(getenv("ISWM_PL2_KORDER")) : -1;
-    const int gc = dgrad ? a.Cout : a.Cin;
-    const bool can = a.pad < 4 && a.stride == 1 && a.KH * a.KW > 1 && gc >= 128;
-    if (!can || force == 0) return 0;
-    if (force == 1) return 1;
-    return (wide && a.M >= 60000) ? 1 : 0;
-}
 bool launch_conv_pl2(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw);
 size_t packed_weight_bytes_pl2(int Cout, int T, int Cin, bool dgrad, int planes);
 void launch_pack_weights_pl2(const float* w, void* packed, int Cout, int T, int Cin, bool dgrad, int planes, hipStream_t s);

@@ -851,12 +851,7 @@ extern "C" int iswm_conv2d_kernel_name(const iswm_conv_desc* d, int kind, char* 
         const int cols = dg ? d->Cin : d->Cout;
         int rbw, wide;
         conv_pl2_plan(dg ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->Ho * d->Wo, cols, pl2_K(d, dg), pl2_wide_ok(d, dg), &rbw, &wide);
-        if (wide) {
-            ConvArgs a = base_args(d);
-            a.M = dg ? d->N * d->H * d->W : d->N * d->Ho * d->Wo;
-            const bool kmaj = rbw == 10 && pl2_korder(a, dg, true) != 0;
-            snprintf(buf, buflen, "k_conv_pl2w<%d, %d, %s, %s>", rbw, math_planes(), dg ? "true" : "false", kmaj ? "true" : "false");
-        }
+        if (wide) snprintf(buf, buflen, "k_conv_pl2w<%d, %d, %s>", rbw, math_planes(), dg ? "true" : "false");
         else if (cols <= 64) snprintf(buf, buflen, "k_conv_pl2<%d, 2, %d, %s, false, 0>", rbw / 2, math_planes(), dg ? "true" : "false");
         else snprintf(buf, buflen, "k_conv_pl2<%d, 1, %d, %s, false, 0>", rbw, math_planes(), dg ? "true" : "false");
         return 0;

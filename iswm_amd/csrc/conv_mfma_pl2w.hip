@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4w mfma16w(uint4 a, uint4 b, f32x4w c) {
 // Row-major rows only (no parity classes: strided data gradients stay on k_conv_pl2).  PERSISTENT like k_conv_pl2.
 // (Static s_setprio 1 for waves 4-7, and priorities swapped between the two waves of a SIMD every row block, were measured
 // equal or slower: profiles/r03_pl2w_ab.txt.)
-template <int RBW, int NP, bool DGRAD, bool KMAJ = false>
+template <int RBW, int NP, bool DGRAD>
 __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
     const int GC = DGRAD ? a.Cout : a.Cin;
     const int NC = DGRAD ? a.Cin : a.Cout;
@@ -125,25 +125,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
         if (a.pad < 4) return true;                       // the vote only where padding is deep (ASPP rates)
         return __syncthreads_or(any) != 0;
     };
-    // K order of a tile's stages: tap-major (all channel chunks of a tap, then the next tap: one pointer set-up per tap) or, korder = 1,
-    // CHUNK-major (all taps of a 64-channel chunk, then the next chunk): the taps of a KxK filter read the same input rows shifted by
-    // a pixel or a row, so with the taps innermost a workgroup re-reads a window of (tile + halo) x 64 channels while it is still in
-    // L2 instead of (tile + halo) x all channels -- on the 129x129 maps the first form missed L2 on every tap (6x the operand bytes
-    // crossed the fabric).  Only where no tap can be skipped (pad < 4: the host sets it).
-    // COMPILE-TIME (KMAJ): as a run-time flag the extra path in next_in_tile slowed every instantiation of the stage loop by 2-3 %
-    constexpr bool kmaj = KMAJ;
-    int tap = -1, cc = kmaj ? 0 : nCC - 1;
+    int tap = -1, cc = nCC - 1;
     auto next_in_tile = [&]() __attribute__((always_inline)) -> bool {
-        if constexpr (kmaj) {
-            if (++tap >= taps) {
-                tap = 0;
-                if (++cc >= nCC) return false;
-            }
-            setup_tap(tap);
-#pragma unroll
-            for (int i = 0; i < NRG; ++i) aptr[i] += cc * astep[i];
-            return true;
-        }
         if (++cc < nCC) return true;
         cc = 0;
         do {
@@ -443,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pl2w(const ConvArgs a) {
         if (i_tile >= ntiles) return false;
         load_tile(i_tile);
         tap = -1;
-        cc = kmaj ? 0 : nCC - 1;
+        cc = nCC - 1;
         return true;
     };
     auto next_tile_stage = [&]() __attribute__((always_inline)) -> bool {
@@ -505,7 +488,6 @@ bool launch_conv_pl2w(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw
     a.MT = (a.M + rbw * 16 - 1) / (rbw * 16);
     a.NT = (nc + 255) / 256;
     a.psplit = 1;
-    a.korder = rbw == 10 ? pl2_korder(a, dgrad, true) : 0;
     const int tiles = a.MT * a.NT;
     dim3 grid(tiles < ncu ? tiles : ncu), blk(512);
 #define PL2W_LAUNCH(R)                                                                     \
@@ -515,10 +497,7 @@ bool launch_conv_pl2w(ConvArgs a, hipStream_t s, bool dgrad, int planes, int rbw
     } while (0)
     if (rbw == 8) PL2W_LAUNCH(8);
     else if (rbw == 9) PL2W_LAUNCH(9);
-    else if (rbw == 10 && a.korder) {                 // chunk-major K order: the 129 x 129 maps (pl2_korder)
-        if (dgrad) hipLaunchKernelGGL((k_conv_pl2w<10, 3, true, true>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((k_conv_pl2w<10, 3, false, true>), grid, blk, 0, s, a);
-    } else if (rbw == 10) PL2W_LAUNCH(10);
+    else if (rbw == 10) PL2W_LAUNCH(10);
     else return false;
 #undef PL2W_LAUNCH
     return true;
