@@ -560,9 +560,21 @@ __global__ __launch_bounds__(64 * (MW + 4), (MW + 4) / 4) void k_wgrad_pls(const
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tiles = a.MT * a.NT;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = L / tiles, tile = L - split * tiles;
-    const int mt = tile / a.NT;
+    int split = L / tiles, tile = L - split * tiles;
+    int mt = tile / a.NT;
     int nt = tile - mt * a.NT;
+    if (a.rect == 2) {
+        // eight 256-channel column blocks, eight XCDs: XCD x (workgroups x, x + 8, ...) takes column block x of EVERY tap, walked
+        // split-major (image range), then taps heaviest first, then the row tiles -- the taps of a block read the same rows of
+        // the input shifted by the dilation, and now find them in their XCD's L2 (1.7 MB per image and block).  With the generic
+        // order an XCD held all eight blocks of five taps (13 MB per image): every tap re-read the input through the fabric,
+        // 6-10x the operand bytes (profiles/r03_pmc/traffic_by_geometry.txt).
+        const int idx = blockIdx.x >> 3, per_split = (a.NT >> 3) * a.MT;
+        split = idx / per_split;
+        const int rem = idx - split * per_split;
+        mt = rem % a.MT;
+        nt = (rem / a.MT) * 8 + (blockIdx.x & 7);              // (tap slot) * chunks + column block
+    }
     // rect mode: this tile's tap, its rectangle of output pixels and the part of it this split walks
     int r_oh0 = 0, r_ow0 = 0, r_h = a.Ho, r_w = a.Wo, r_dh = 0, r_dw = 0;
     int p_begin = split * a.psplit;
@@ -993,7 +1005,7 @@ extern "C" int iswm_conv2d_wgrad_planes_ok(const iswm_conv_desc* d) {
 
 // Tap-rectangle mode of k_wgrad_pls (WgArgs::rect): deep padding, stride 1, whole taps per 256-column tile.  Returns the mean
 // number of pixels a tile walks (what the split planner balances) and fills the taps by descending rectangle size.
-static bool wgrad_rect_mode(const iswm_conv_desc* d, int64_t* p_eff, unsigned char* order) {
+static bool wgrad_rect_mode(const iswm_conv_desc* d, int64_t* p_eff, unsigned char* order, bool* similar = nullptr) {
     static int on = -1;
     if (on < 0) on = getenv("ISWM_WG_RECT") ? atoi(getenv("ISWM_WG_RECT")) : 1;
     const int taps = d->KH * d->KW;
@@ -1013,6 +1025,14 @@ static bool wgrad_rect_mode(const iswm_conv_desc* d, int64_t* p_eff, unsigned ch
                 if (area[order[j]] > area[order[i]]) std::swap(order[i], order[j]);
     }
     if (p_eff) *p_eff = std::max<int64_t>(32, sum / taps);
+    if (similar) {              // are the taps' rectangles of similar size (smallest >= 35 % of the largest)?
+        int64_t lo = area[0], hi = area[0];
+        for (int t = 1; t < taps; ++t) {
+            lo = std::min(lo, area[t]);
+            hi = std::max(hi, area[t]);
+        }
+        *similar = 100 * lo >= 35 * hi;
+    }
     return true;
 }
 
@@ -1059,7 +1079,16 @@ extern "C" int iswm_conv2d_wgrad_planes(const iswm_conv_desc* d, const void* xp,
     const int wide = wgrad_pl_wide(a.Ktot, d->KH * d->KW, a.P);
     a.NT = wide ? (a.Ktot + 255) / 256 : (a.Ktot + 127) / 128;
     int64_t p_plan = a.P;
-    a.rect = (wide && wgrad_rect_mode(d, &p_plan, a.tap_order)) ? 1 : 0;
+    bool similar = false;
+    a.rect = (wide && wgrad_rect_mode(d, &p_plan, a.tap_order, &similar)) ? 1 : 0;
+    {
+        // one column block per XCD (k_wgrad_pls) where the taps walk their rectangles at a similar pace (rates 6 and 12 on the
+        // 33 x 33 map: fabric fetch -43 % / -27 %, kernel -4.6 % / -2.2 %; at rate 18 the corner taps are a fifth of the centre
+        // tap, the XCD's taps drift apart by images and the order only unbalances the rounds: +3 %) -- profiles/r03_rect_xcd.txt
+        static int rx = -2;
+        if (rx == -2) rx = getenv("ISWM_WG_RECT_XCD") ? atoi(getenv("ISWM_WG_RECT_XCD")) : -1;    // tuning switch: 0 never, 1 always
+        if (a.rect && (d->Cin >> 8) == 8 && (rx == 1 || (rx < 0 && similar))) a.rect = 2;
+    }
     plan_wgrad_pl(d->Cout, a.Ktot, d->KH * d->KW, p_plan, &a.nsplit, &a.psplit);
     static int abl = -1;
     if (abl < 0) abl = getenv("ISWM_WG_ABL") ? atoi(getenv("ISWM_WG_ABL")) : 0;
