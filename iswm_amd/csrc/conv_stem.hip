@@ -403,14 +403,21 @@ static int stem_wgrad_grid(const ConvArgs& a, int* per) {
     return (int)((M + *per - 1) / *per);
 }
 
+static bool stem_wgrad_on() {
+    static int on = -1;
+    if (on < 0) on = (getenv("ISWM_STEM_WG") && getenv("ISWM_STEM_WG")[0] == '0') ? 0 : 1;      // tuning switch
+    return on != 0;
+}
+
 size_t stem_wgrad_workspace(const ConvArgs& a) {
+    if (!stem_wgrad_on()) return 0;          // 0: the generic weight gradient runs (and sizes its own workspace)
     int per;
     return (size_t)stem_wgrad_grid(a, &per) * 64 * 224 * sizeof(float);
 }
 
 // a.x: NHWC4 fp32 image, a.y: dy [M][ldy] fp32; dw: OHWI [64][7][7][4]; workspace >= stem_wgrad_workspace
 bool launch_stem_wgrad(ConvArgs a, float* dw, float* workspace, hipStream_t s) {
-    if (!stem_geometry(a)) return false;
+    if (!stem_geometry(a) || !stem_wgrad_on()) return false;
     int per;
     const int grid = stem_wgrad_grid(a, &per);
     a.M = a.N * a.Ho * a.Wo;

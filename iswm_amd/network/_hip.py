@@ -24,6 +24,9 @@ from .. import ops
 # Test hook: when set to a dict, cba_fwd records {bn_module: (out > 0)} for every fused ReLU so a
 # parity test can hand the CPU oracle the exact sign pattern this path used (tests/test_hip_modules.py).
 MASK_RECORDER = None
+# ... and {MaxPool2d module: uint8 NHWC tap index (kh * 3 + kw) chosen per output element}: two fp32 implementations pick different
+# elements of a near-tie, which re-routes that window's gradient (same kind of discontinuity as a flipped ReLU)
+POOL_RECORDER = None
 
 
 def pad4(c):

@@ -116,6 +116,8 @@ class MaxPool2d(_hip.HipModule, nn.MaxPool2d):
             raise NotImplementedError("HIP max-pool is the stem's 3x3 / stride 2 / pad 1")
         # layer1 follows: its 1x1 convs take the pooled map pre-split
         y, idx = ops.maxpool_fwd(x, planes=ops.planes_on() and x.shape[3] % 64 == 0)
+        if _hip.POOL_RECORDER is not None:
+            _hip.POOL_RECORDER[self] = idx
         self._saved = (idx, tuple(x.shape)) if save else None
         return y
 

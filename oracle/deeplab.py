@@ -43,6 +43,10 @@ class OracleDeepLab:
         # the ~1e-6 fraction of pre-activations that are within rounding of zero, and one flipped
         # ReLU changes a small-batch gradient by O(1/pixels) -- a discontinuity, not an error.
         self.relu_masks = None
+        # Optional [N,C,Ho,Wo] tap index (kh * 3 + kw) per output element of the stem's MaxPool: when given, the pool takes THAT
+        # element of each window instead of its own argmax (the HIP path's choice; same reason as relu_masks: a near-tie between two
+        # window elements is decided differently by two fp32 evaluations, and the window's gradient then goes to another pixel)
+        self.pool_index = None
         self.preact = None          # when a dict: records every ReLU input (for near-tie margins)
 
     # -- nn.Module-like helpers -------------------------------------------------
@@ -125,7 +129,10 @@ class OracleDeepLab:
         (network/utils.py:78-93, network/backbone/resnet.py:144-155)."""
         x = self._conv(x, "backbone.conv1.weight", 2, 3)
         x = self._relu(self._bn(x, "backbone.bn1"), "backbone.bn1", store=False)
-        x = self._store(F.max_pool2d(x, 3, 2, 1))
+        if self.pool_index is not None:
+            self.pool_gap = float((F.max_pool2d(x, 3, 2, 1) - _pool_select(x, self.pool_index)).detach().abs().max() /
+                                  x.detach().abs().max())          # how far the imposed choices are from this evaluation's maxima
+        x = self._store(F.max_pool2d(x, 3, 2, 1) if self.pool_index is None else _pool_select(x, self.pool_index))
         feats = OrderedDict()
         for li, L in enumerate(self.cfg.layers()):
             for bi, d in enumerate(L["dils"]):
@@ -175,6 +182,14 @@ class OracleDeepLab:
         return F.interpolate(y, size=input_shape, mode="bilinear", align_corners=False)
 
     __call__ = forward
+
+
+def _pool_select(x, index):
+    """MaxPool2d(3, stride 2, padding 1) (network/backbone/resnet.py:148) with the window element named by `index`"""
+    xp = F.pad(x, (1, 1, 1, 1), value=float("-inf"))
+    win = xp.unfold(2, 3, 2).unfold(3, 3, 2)                     # [N, C, Ho, Wo, 3, 3]
+    win = win.reshape(win.shape[:4] + (9,))
+    return win.gather(4, index.long().unsqueeze(-1)).squeeze(-1)
 
 
 class _Bf16Conv(torch.autograd.Function):
