@@ -67,16 +67,24 @@ class record_masks:
 
     def __enter__(self):
         from iswm_amd.network import _hip
-        _hip.MASK_RECORDER = self.rec
+        self.pools = {}
+        _hip.MASK_RECORDER, _hip.POOL_RECORDER = self.rec, self.pools
         return self
 
     def __exit__(self, *a):
         from iswm_amd.network import _hip
-        _hip.MASK_RECORDER = None
+        _hip.MASK_RECORDER = _hip.POOL_RECORDER = None
 
     def masks(self):
         names = {m: n for n, m in self.module.named_modules()}
         return {self.prefix + names[bn]: v.permute(0, 3, 1, 2).cpu() for bn, v in self.rec.items()}
+
+    def apply_to(self, o):
+        """hand the oracle this path's ReLU sign patterns and (whole models) the stem max-pool's window choices, and make it
+        record its pre-activations; check_sign_patterns() then verifies that every imposed decision is a near-tie"""
+        o.relu_masks, o.preact = self.masks(), {}
+        if self.pools:
+            o.pool_index = next(iter(self.pools.values())).permute(0, 3, 1, 2).cpu()
 
 
 def check_sign_patterns(o, masks):
@@ -90,6 +98,7 @@ def check_sign_patterns(o, masks):
         if mism.any():
             assert float(z[mism].abs().max()) <= RTOL * float(z.abs().max()), site
     assert bad <= max(3, 1e-4 * total), (bad, total)
+    assert getattr(o, "pool_gap", 0.0) <= RTOL, o.pool_gap        # imposed max-pool choices: near-ties of the oracle's own maxima
     return bad, total
 
 
@@ -129,7 +138,7 @@ def test_aspp(tag, rates, hw):
         check_grad_robust(p.grad, fx, "grad." + k)
     # same-mask: element-wise 1e-3 against the oracle
     o = oracle_for(sd, rates)
-    o.relu_masks, o.preact = rec.masks(), {}
+    rec.apply_to(o)
     xo = x.clone().requires_grad_(True)
     yo = o.aspp(xo, "aspp")
     (yo * up).sum().backward()
@@ -164,7 +173,7 @@ def test_head_v3plus():
     for k, p in m.named_parameters():
         check_grad_robust(p.grad, fx, "grad." + k)
     o = oracle_for(sd)
-    o.relu_masks, o.preact = rec.masks(), {}
+    rec.apply_to(o)
     lo_, ho_ = low.clone().requires_grad_(True), hi.clone().requires_grad_(True)
     yo = o.head({"low_level": lo_, "out": ho_})
     (yo * up).sum().backward()
@@ -203,7 +212,7 @@ def test_bottleneck():
             if k.startswith(tag + ".buf."):
                 assert rel_err(m.state_dict()[k[len(tag) + 5:]], fx[k]) <= RTOL, k
         o = oracle_for(sd)
-        o.relu_masks, o.preact = rec.masks(), {}
+        rec.apply_to(o)
         xo = x.clone().requires_grad_(True)
         yo = o._bottleneck(xo, "block", s, d, down)
         (yo * up).sum().backward()
@@ -286,7 +295,7 @@ def test_whole_model(tag, backbone, os_):
     up = upstream(lg4.shape, 12)
     lg4.backward(up.to(dev()))
     o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
-    o.relu_masks, o.preact = rec.masks(), {}
+    rec.apply_to(o)
     lgo = o(x4)
     assert rel_err(lg4, lgo.detach()) <= RTOL
     lgo.backward(up)
@@ -334,7 +343,7 @@ def test_train_steps_match_oracle():
         opt.zero_grad()
         l.backward()
         opt.step()
-        o.relu_masks, o.preact = rec.masks(), {}
+        rec.apply_to(o)
         lo = oloss.weighted_ce(o(x), lab, w)
         o.zero_grad()
         lo.backward()
@@ -391,7 +400,7 @@ def test_full_size_step_vs_oracle():
         p.grad = None
     loss.backward()
     o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
-    o.relu_masks, o.preact = rec.masks(), {}
+    rec.apply_to(o)
     lgo = o(x)
     assert rel_err(lg, lgo.detach()) <= RTOL
     lo = oloss.weighted_ce(lgo, lab, w)
@@ -613,7 +622,7 @@ def test_whole_model_v3_head_5_channel_stem():
     up = upstream(lg.shape, 14)
     lg.backward(up.to(dev()))
     o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
-    o.relu_masks, o.preact = rec.masks(), {}
+    rec.apply_to(o)
     lgo = o(x)
     lgo.backward(up)
     check_sign_patterns(o, o.relu_masks)
@@ -708,7 +717,7 @@ def test_bf16_mixed_precision_mode():
             o = oracle_for(bsd)
             o.conv_math = "bf16"
             o.act_bf16 = True
-            o.relu_masks, o.preact = rec.masks(), {}
+            rec.apply_to(o)
             xo = xb.clone().requires_grad_(True)
             yo = o._bottleneck(xo, "block", stride, dil, down)
             assert close_up_to_bf16_ties(y, yo)
@@ -728,7 +737,7 @@ def test_bf16_mixed_precision_mode():
         o = oracle_for(asd)
         o.conv_math = "bf16"
         o.act_bf16 = True
-        o.relu_masks, o.preact = rec.masks(), {}
+        rec.apply_to(o)
         xo = xa.clone().requires_grad_(True)
         yo = o.aspp(xo, "aspp")
         assert close_up_to_bf16_ties(y, yo)
@@ -877,7 +886,7 @@ def test_fix_bn_training_step():
         if "running" in k or "num_batches" in k:
             assert torch.equal(v.cpu(), sd[k]), k                # frozen statistics
     o = OracleDeepLab(cfg, sd, dropout_p=0.0).eval()
-    o.relu_masks, o.preact = rec.masks(), {}
+    rec.apply_to(o)
     lgo = o(x)
     assert rel_err(lg, lgo.detach()) <= RTOL
     w = torch.tensor([1.0, 3.0])
@@ -961,7 +970,7 @@ def test_num_classes_21_and_batch_one():
     with record_masks(m, "") as rec:
         lg = m(x.to(dev()))
     o = OracleDeepLab(cfg, sd, dropout_p=0.0).train()
-    o.relu_masks, o.preact = rec.masks(), {}
+    rec.apply_to(o)
     lgo = o(x)
     assert lg.shape == (4, 21, 65, 65) and rel_err(lg, lgo.detach()) <= RTOL
     loss = CrossEntropyLoss(weight=w, ignore_index=255)(lg, lab.to(dev()))
