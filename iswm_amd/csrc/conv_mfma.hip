@@ -1255,7 +1255,10 @@ extern "C" int iswm_conv2d_dgrad_pl2_bn(const iswm_conv_desc* d, const void* dyp
 
 extern "C" size_t iswm_conv2d_wgrad_workspace(const iswm_conv_desc* d) {
     if (!d) return 0;
-    if (conv_math() == 1 && stem_geometry(base_args(d)) && stem_wgrad_workspace(base_args(d)) > 0) return stem_wgrad_workspace(base_args(d));
+    if (conv_math() == 1 && stem_geometry(base_args(d))) {
+        const size_t stem = stem_wgrad_workspace(base_args(d));          // 0: the stem's own weight gradient is switched off
+        if (stem > 0) return stem;
+    }
     WgradPlan p = plan_wgrad(d, conv_math() >= 1);
     if (p.nsplit <= 1) return 0;
     return (size_t)p.nsplit * d->Cout * d->KH * d->KW * d->Cin * sizeof(float);
