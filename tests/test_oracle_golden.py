@@ -275,3 +275,24 @@ def test_bf16_conv_oracle_definition():
     assert torch.equal(y2.detach(), F.conv2d(x, w, None, 1, 2, 2))
     y2.backward(dy)
     assert rel_err(xb.grad, torch.nn.grad.conv2d_input(x.shape, w, dy, 1, 2, 2)) <= 1e-6
+
+
+def test_oracle_pool_select_is_maxpool_for_its_own_argmax():
+    """OracleDeepLab.pool_index (the HIP path's max-pool window choices, imposed in smoke() and the same-mask tests): with the
+    oracle's OWN argmax as index, _pool_select must reproduce nn.MaxPool2d(3, 2, 1) (network/backbone/resnet.py:148) bit for
+    bit, and route the gradient to the same pixels (a pixel that wins several overlapping windows sums their gradients in
+    another order: equal to rounding)."""
+    import torch.nn.functional as F
+    from oracle.deeplab import _pool_select
+    x = torch.randn(2, 5, 9, 11, generator=torch.Generator().manual_seed(4), requires_grad=True)
+    y, ind = F.max_pool2d(x, 3, 2, 1, return_indices=True)
+    ho, wo = y.shape[2:]
+    oh = torch.arange(ho).view(1, 1, ho, 1)
+    ow = torch.arange(wo).view(1, 1, 1, wo)
+    tap = ((ind // 11 - (2 * oh - 1)) * 3 + (ind % 11 - (2 * ow - 1))).to(torch.uint8)
+    ys = _pool_select(x, tap)
+    assert torch.equal(ys, y)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    (gx,) = torch.autograd.grad(ys, x, g, retain_graph=True)
+    (gr,) = torch.autograd.grad(y, x, g)
+    assert torch.equal(gx != 0, gr != 0) and rel_err(gx, gr) < 1e-6
