@@ -306,6 +306,18 @@ int iswm_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t M
                        iswm_stream_t stream);
 int iswm_add_inplace(float* dst, const float* src, int64_t n, iswm_stream_t stream);
 int iswm_scale_inplace(float* x, int64_t n, const float* scalar_dev, float host_mul, iswm_stream_t stream);
+/* The heads' last two layers with the 1x1 classifier folded into the BatchNorm passes of the stage in front of it --
+ * Conv2d(256, 256, 3) -> BatchNorm2d -> ReLU -> Conv2d(256, num_classes, 1), network/_deeplab.py:44-52 (DeepLabHeadV3Plus) and
+ * :84-90 (DeepLabHead): forward = one pass over the raw conv output y to logits [M][4] (the 256-channel activation is never
+ * stored); backward = the stage's BatchNorm backward fed by dlogit [M][4] and the zero-padded classifier weight wc4 [4][C],
+ * returning the classifier's weight gradient dwc4 with it.  C == 256, num_classes <= 4. */
+int iswm_bn_apply_classify(const float* y, int64_t M, int C, int ldy, const float* scale, const float* shift, const float* mean,
+                           const float* wc4, const float* bias4, float* logits, int ldl, iswm_stream_t stream);
+size_t iswm_bn_classify_bwd_workspace(int64_t M, int C);
+int iswm_bn_backward_classify(const float* dlogit, int ldl, const float* wc4, const float* y, int ldy, int64_t M, int C,
+                              const float* mean, const float* invstd, const float* gamma, const float* mask_scale,
+                              const float* mask_shift, int training, float* dgamma, float* dbeta, float* dwc4, void* dy, int lddy,
+                              int64_t dy_ps, void* workspace, size_t workspace_bytes, iswm_stream_t stream);
 /* Convolutions whose channel counts are not multiples of the kernels' granule (nn.Conv2d(3, 64, 7) at network/backbone/resnet.py:137,
  * Conv2d(304, 256, 3) / Conv2d(256, 48, 1) / Conv2d(256, num_classes, 1) at network/_deeplab.py:36-52): zero-padded OHWI copy of an OIHW
  * parameter with element strides[4] = (O, I, H, W); the inverse for its gradient; zero bytes [byte0, byte1) of every row of a

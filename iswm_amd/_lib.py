@@ -101,6 +101,10 @@ _SIGS = {
     "iswm_copy_channels": (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
     "iswm_add_inplace": (c_int, [P, P, c_int64, P]),
     "iswm_scale_inplace": (c_int, [P, c_int64, P, c_float, P]),
+    "iswm_bn_apply_classify": (c_int, [P, c_int64, c_int, c_int, P, P, P, P, P, P, c_int, P]),
+    "iswm_bn_classify_bwd_workspace": (c_size_t, [c_int64, c_int]),
+    "iswm_bn_backward_classify": (c_int, [P, c_int, P, P, c_int, c_int64, c_int, P, P, P, P, P, c_int, P, P, P, P, c_int, c_int64,
+                                          P, c_size_t, P]),
     "iswm_pad_weights": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P]),
     "iswm_unpad_weights": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "iswm_fill_zero": (c_int, [P, c_size_t, P]),

@@ -554,6 +554,67 @@ class WeightPacker(object):
             e["live"] = False
 
 
+_CLS_FUSE = os.environ.get("ISWM_CLS_FUSE", "1") != "0"      # tuning switch: 0 = the classifier as a conv of its own
+
+
+def cls_fusable(conv, bn, relu, cls):
+    """[Conv2d(.., 256, k) -> BatchNorm2d -> ReLU] followed by the 1x1 classifier Conv2d(256, num_classes <= 4, 1): the tail of both
+    DeepLab heads (network/_deeplab.py:44-52, 84-90).  The classifier is then folded into the stage's BatchNorm passes
+    (csrc/bn_classify.hip).  Not while a test records ReLU patterns (it needs the stage's stored output)."""
+    return (_CLS_FUSE and MASK_RECORDER is None and relu is True and type(conv) is Conv2d and conv.out_channels == 256 and
+            conv.bias is None and type(cls) is Conv2d and cls.in_channels == 256 and cls.out_channels <= 4 and
+            tuple(cls.kernel_size) == (1, 1) and tuple(cls.stride) == (1, 1) and tuple(cls.padding) == (0, 0) and
+            bn.momentum is not None and bn.track_running_stats and bn.affine)
+
+
+def cba_cls_fwd(conv, bn, cls, x, save):
+    """conv -> BatchNorm -> ReLU -> 1x1 classifier with the activation never stored: returns (logits [N,H,W,4], ctx)"""
+    g = conv.geometry(x)
+    training = bn.training
+    y, partials, tiles = ops.conv2d_fwd(x, conv.ohwi(), g, want_stats=training, wpk=conv.packed(0), wpk2=conv.packed2(0))
+    if training:
+        count = y.shape[0] * y.shape[1] * y.shape[2]
+        if count <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(y.shape),))
+        coef = ops.bn_finalize(partials, tiles[0], count, tiles[1], bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               bn.momentum, bn.eps)
+        if not getattr(bn, "_iswm_nbt_fused", False):
+            bn.num_batches_tracked.add_(1)
+    else:
+        coef = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    wc4 = ops.pad_weights(cls.weight, 4, 256).view(4, 256)
+    b4 = None if cls.bias is None else ops.pad_weights(cls.bias.view(-1, 1, 1, 1), 4, 1).view(-1)
+    logits = ops.bn_apply_classify(y, coef, wc4, b4)
+    ctx = dict(x=x, y=y, coef=coef, g=g, training=training, wc4=wc4, cls=cls, cls_fused=True) if save else None
+    return logits, ctx
+
+
+def cba_cls_bwd(conv, bn, ctx, dlogit, sink, need_dx=True, dx=None, accumulate=False):
+    """backward of cba_cls_fwd: classifier bias / weight gradients, the stage's BatchNorm backward fed by dlogit, then the
+    conv's weight and data gradients as in cba_bwd"""
+    cls, x, y, g = ctx["cls"], ctx["x"], ctx["y"], ctx["g"]
+    dlogit = ops.as_f32(dlogit)
+    if cls.bias is not None and cls.bias.requires_grad:
+        ops.unpad_weights(ops.colsum(dlogit).view(-1, 1, 1, 1), sink.target(cls.bias).view(-1, 1, 1, 1))
+        sink.done(cls.bias)
+    gw, gb = bn.weight, bn.bias
+    dgamma = sink.target(gw) if gw.requires_grad else torch.empty_like(gw)
+    dbeta = sink.target(gb) if gb.requires_grad else torch.empty_like(gb)
+    dyp = ops.planes_conv_ok(conv.cin_p, conv.cout_p, 1)
+    dy, dwc4 = ops.bn_backward_classify(dlogit, ctx["wc4"], y, ctx["coef"], gw, ctx["training"], dgamma, dbeta, dyp)
+    if gw.requires_grad:
+        sink.done(gw)
+    if gb.requires_grad:
+        sink.done(gb)
+    if cls.weight.requires_grad:
+        ops.unpad_weights(dwc4.view(4, 1, 1, 256), sink.target(cls.weight))
+        sink.done(cls.weight)
+    conv.write_wgrad(x, dy, g, sink)
+    if not need_dx:
+        return None
+    return ops.conv2d_dgrad(dy, conv.ohwi(), g, tuple(x.shape), dx, accumulate, wpk=conv.packed(1), wpk2=conv.packed2(1))
+
+
 class SeparableBase(HipModule):
     """marker base of _deeplab.AtrousSeparableConvolution (body = [DepthwiseConv2d, pointwise Conv2d]) so that the
     conv -> BN -> ReLU stage logic here can recognise it without importing _deeplab"""
@@ -595,6 +656,14 @@ class HipSequential(HipModule, nn.Sequential):
         ctxs = []
         for k, s in enumerate(st):
             last = k == len(st) - 1
+            if ctxs and ctxs[-1] == "FOLDED" and last:
+                break                                   # the classifier conv was folded into the stage in front of it
+            if (s[0] == "cba" and k == len(st) - 2 and st[k + 1][0] == "conv" and out is None and
+                    cls_fusable(s[1], s[2], s[3], st[k + 1][1])):
+                x, c = cba_cls_fwd(s[1], s[2], st[k + 1][1], x, save)
+                ctxs.append(c)
+                ctxs.append("FOLDED")
+                continue
             if s[0] == "cba":
                 # the stage's output is pre-split when the next stage is a convolution; the last stage follows `out`
                 # / out_fmt (default fp32: the caller is not a conv unless it says so)
@@ -621,6 +690,11 @@ class HipSequential(HipModule, nn.Sequential):
         for k in range(len(st) - 1, -1, -1):
             s = st[k]
             first = k == 0
+            if ctxs[k] == "FOLDED":
+                continue
+            if s[0] == "cba" and ctxs[k] is not None and ctxs[k].get("cls_fused"):
+                dy = cba_cls_bwd(s[1], s[2], ctxs[k], dy, sink, need_dx or not first, dx if first else None, accumulate and first)
+                continue
             if s[0] == "cba":
                 dy, _ = cba_bwd(s[1], s[2], ctxs[k], dy, sink, need_dx or not first, dx if first else None,
                                 accumulate and first)

@@ -769,6 +769,31 @@ def bn_backward(dout, out, y, coef, gamma, relu, training, dgamma, dbeta, want_d
     return dy, dres
 
 
+def bn_apply_classify(y, coef, wc4, bias4):
+    """logits [N,H,W,4] = bias4 + wc4 . relu(bn(y)) in one pass over the raw conv output y (csrc/bn_classify.hip); wc4 = the 1x1
+    classifier's weight zero-padded to [4, C] (pad_weights), C == 256"""
+    m, c, ldy = rows(y)
+    out = torch.empty(tuple(y.shape[:3]) + (4,), dtype=torch.float32, device=y.device)
+    call("iswm_bn_apply_classify", _p(y), m, c, ldy, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(wc4), _p(bias4), _p(out), 4, _stream())
+    return out
+
+
+def bn_backward_classify(dlogit, wc4, y, coef, gamma, training, dgamma, dbeta, dy_planes):
+    """BatchNorm + ReLU backward of the stage whose activation fed the folded classifier: returns (dy, dwc4) -- dy the gradient of
+    the raw conv output (Planes when dy_planes), dwc4 [4, C] the classifier's weight gradient"""
+    m, c, ldy = rows(y)
+    _, cl, ldl = rows(dlogit)
+    assert cl == 4
+    need = _lib.load().iswm_bn_classify_bwd_workspace(m, c)
+    ws = torch.empty((need // 8,), dtype=torch.float64, device=y.device)
+    dy = new_planes(*y.shape, y.device) if dy_planes else torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    pdy, _, _, lddy, psdy = xrows(dy)
+    dwc4 = torch.empty((4, c), dtype=torch.float32, device=y.device)
+    call("iswm_bn_backward_classify", _p(dlogit), ldl, _p(wc4), _p(y), ldy, m, c, _p(coef[2]), _p(coef[3]), _p(gamma), _p(coef[0]),
+         _p(coef[1]), int(bool(training)), _p(dgamma), _p(dbeta), _p(dwc4), _p(pdy), lddy, psdy, _p(ws), need, _stream())
+    return dy, dwc4
+
+
 def colsum(x):
     """per-channel sum over all pixels (bias gradient)"""
     x = as_f32(x)
